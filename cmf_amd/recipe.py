@@ -1,0 +1,68 @@
+"""Deterministic, build-owned weight recipe: ``w = f(seed, key, shape)``.
+
+Fills every entry of a ``state_dict`` (ours or the reference's -- the key schema is
+identical) from a per-key numpy PCG64 stream, so golden fixtures
+need not store multi-MB weights: the fixture generator loads the recipe into the
+reference with ``load_state_dict(strict=True)`` and the tests load the same recipe into
+the HIP path and the oracle.
+
+Distribution choices follow PyTorch's defaults for ``nn.Linear``/``nn.Conv2d``
+(uniform +-1/sqrt(fan_in), as used by the reference's constructors
+``cmf/models/components/networks.py:116-224``) with non-trivial values for the
+parameters the reference initialises to constants (ScaledTanh ``weights``/``bias``,
+``networks.py:96-101``; AffineBijection ``shift``/``log_scale``, ``affine.py:21-22``) so
+that those code paths are exercised by parity tests.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+__all__ = ["fill_state_dict", "recipe_tensor"]
+
+
+def _rng(key, seed):
+    return np.random.Generator(np.random.PCG64((zlib.crc32(key.encode()) + 1000003 * (seed + 1)) % (2 ** 63)))
+
+
+def recipe_tensor(key, shape, dtype, seed, sibling_shapes=None):
+    """Return the recipe value for one state-dict entry, or ``None`` to keep the
+    constructor's value (structural buffers: masks, Gaussian mean/stddev)."""
+    shape = tuple(shape)
+    rng = _rng(key, seed)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "permutation":
+        return torch.from_numpy(rng.permutation(shape[0]).astype(np.int64))
+    if leaf == "inverse_permutation":
+        perm = _rng(key[: -len("inverse_permutation")] + "permutation", seed).permutation(shape[0])
+        return torch.from_numpy(np.argsort(perm).astype(np.int64))
+    if leaf in ("mask", "mean", "stddev"):
+        return None
+    if leaf == "_fixed_samples":
+        return torch.from_numpy(rng.standard_normal(shape)).to(dtype)
+    if leaf in ("shift", "log_scale"):          # AffineBijection (2-D prior)
+        return torch.from_numpy(rng.uniform(-0.3, 0.3, shape)).to(dtype)
+    if leaf == "weights":                       # ScaledTanh2dModule scale
+        return torch.from_numpy(rng.uniform(0.4, 0.8, shape)).to(dtype)
+    if leaf == "bias" and len(shape) == 3:      # ScaledTanh2dModule offset (C,1,1)
+        return torch.from_numpy(rng.uniform(-0.05, 0.05, shape)).to(dtype)
+    if leaf == "weight":
+        fan_in = int(np.prod(shape[1:]))
+        b = 1.0 / np.sqrt(fan_in)
+        return torch.from_numpy(rng.uniform(-b, b, shape)).to(dtype)
+    if leaf == "bias":
+        wshape = (sibling_shapes or {}).get(key[:-4] + "weight")
+        fan_in = int(np.prod(wshape[1:])) if wshape is not None else shape[0]
+        b = 1.0 / np.sqrt(fan_in)
+        return torch.from_numpy(rng.uniform(-b, b, shape)).to(dtype)
+    raise KeyError(f"recipe has no rule for state-dict key {key!r} of shape {shape}")
+
+
+def fill_state_dict(state_dict, seed=0):
+    """Return a new state dict with the same keys/shapes/dtypes filled by the recipe."""
+    shapes = {k: tuple(v.shape) for k, v in state_dict.items()}
+    out = {}
+    for k, v in state_dict.items():
+        t = recipe_tensor(k, v.shape, v.dtype, seed, shapes)
+        out[k] = v.detach().clone() if t is None else t.reshape(v.shape).to(v.dtype)
+    return out

@@ -1,0 +1,153 @@
+"""Hyper-parameters and layer schemas of the non-square configurations on the hot path.
+
+The reference derives a flat "schema" (list of layer dicts) from a config dict
+(``config/schemas.py:1-27``) and ``cmf/models/factory.py`` turns it into nested Density
+modules.  Only the values matter to the log-density path, so they are restated here for
+the BASELINE.json configurations:
+
+  sphere   ``config/two_d.py:175-189,268-310``   flat-realnvp, 5 ACL MLP[10,10], affine prior
+  power/hepmass/... ``config/tabular.py:174-186,279-347``  10 ACL MLP[128]x4, prior 5 ACL MLP[32]x2
+  mnist/cifar10/... ``config/images.py:69-75,120-178``     multiscale RealNVP, ResNet[64]x8 couplers,
+                                                           prior 10 ACL MLP[32]x4, logit pre-processing
+
+``oracle/make_golden.py`` asserts, against the imported reference, that ``get_schema``
+here returns exactly the list the reference builds for the same settings.
+"""
+import copy
+
+__all__ = ["get_config", "get_schema"]
+
+_COMMON = {
+    "non_square": True, "m_flow": False, "num_u_channels": 0,
+    "log_jacobian_method": "cholesky", "hutchinson_distribution": "normal", "hutchinson_samples": 1,
+    "max_cg_iterations": None, "cg_tolerance": 1,
+    "g_kk_loss": False, "g_ij_loss": False, "elbo_regularization_param": 1, "metric_regularization_param": 1,
+    "dequantize": False, "logit_tf_lambda": None, "logit_tf_scale": None,
+}
+
+_TWO_D = {  # config/two_d.py:268-310 (+ :175-189 for the realnvp couplers)
+    **_COMMON, "schema_type": "flat-realnvp", "num_density_layers": 5, "coupler_hidden_channels": [10, 10],
+    "regularization_param": 1, "latent_dimension": 2, "prior": "affine",
+    "likelihood_warmup": False, "likelihood_warmup_start": 500, "likelihood_warmup_end": 1000,
+}
+
+_TABULAR = {  # config/tabular.py:279-347
+    **_COMMON, "schema_type": "flat-realnvp", "num_density_layers": 10, "coupler_hidden_channels": [128] * 4,
+    "regularization_param": 50, "prior": "realnvp", "prior_num_density_layers": 5, "prior_hidden_channels": [32] * 2,
+    "likelihood_warmup": True, "likelihood_warmup_start": 25, "likelihood_warmup_end": 50,
+}
+
+_IMAGES = {  # config/images.py:120-178
+    **_COMMON, "schema_type": "multiscale-realnvp", "g_hidden_channels": [64] * 8, "smaller_realnvp": False,
+    "regularization_param": 50, "log_jacobian_method": "hutch_with_cg", "latent_dimension": 20,
+    "prior": "realnvp", "prior_num_density_layers": 10, "prior_hidden_channels": [32] * 4,
+    "likelihood_warmup": True, "likelihood_warmup_start": 25, "likelihood_warmup_end": 50,
+    "dequantize": True, "logit_tf_scale": 256,
+}
+
+_TABULAR_LATENT = {"power": 2, "gas": 2, "hepmass": 10, "miniboone": 21, "bsds300": 30}   # tabular.py:281-287
+_IMAGE_LAMBDA = {"mnist": 1e-6, "fashion-mnist": 1e-6, "cifar10": 0.05, "svhn": 0.05}    # images.py:69-75
+
+#: x_shape per dataset (images: torchvision shapes; tabular: cmf/datasets/tabular.py after column drops)
+DATA_SHAPES = {
+    "sphere": (3,), "power": (6,), "gas": (8,), "hepmass": (21,), "miniboone": (43,), "bsds300": (63,),
+    "mnist": (1, 28, 28), "fashion-mnist": (1, 28, 28), "cifar10": (3, 32, 32), "svhn": (3, 32, 32),
+}
+
+
+def get_config(dataset, **overrides):
+    """Config dict for ``--model non-square`` on ``dataset`` (reference:
+    ``config.get_config(dataset, "non-square", False)``), restricted to the keys the
+    log-density path reads."""
+    if dataset in _TABULAR_LATENT:
+        cfg = {**_TABULAR, "latent_dimension": _TABULAR_LATENT[dataset]}
+    elif dataset in _IMAGE_LAMBDA:
+        cfg = {**_IMAGES, "logit_tf_lambda": _IMAGE_LAMBDA[dataset]}
+    else:                                      # every 2-D / simulated dataset shares two_d.py's block
+        cfg = dict(_TWO_D)
+    cfg = copy.deepcopy(cfg)
+    cfg["dataset"] = dataset
+    unknown = set(overrides) - set(cfg)
+    if unknown:
+        raise KeyError(f"unknown config keys {sorted(unknown)}")
+    cfg.update(overrides)
+    return cfg
+
+
+def _mlp_coupler(hidden):
+    return {"independent_nets": False,
+            "shift_log_scale_net": {"type": "mlp", "hidden_channels": list(hidden), "activation": "tanh"}}
+
+
+def _flat_realnvp(num_layers, hidden):
+    """config/schemas.py:484-530 with coupler_shared_nets=True and the 'normalise' layers
+    already removed (batch_norm=False for every non-square config, schemas.py:20-21)."""
+    out = [{"type": "flatten"}]
+    for i in range(num_layers):
+        out.append({"type": "acl", "mask_type": "alternating-channel", "reverse_mask": i % 2 != 0,
+                    "coupler": _mlp_coupler(hidden), "num_u_channels": 0})
+    return out
+
+
+def _multiscale_realnvp(hidden, smaller):
+    """config/schemas.py:380-439, non_square=True, resnet_batchnorm=False."""
+    if smaller:
+        base = [("c", False), ("c", True), "squeeze", ("s", False), ("s", True), "split", ("c", False), ("c", True)]
+    else:
+        base = [("c", False), ("c", True), ("c", False), "squeeze", ("s", True), ("s", False), ("s", True), "split",
+                ("c", False), ("c", True), ("c", False), ("c", True)]
+    out = []
+    for item in base:
+        if item == "squeeze":
+            out.append({"type": "squeeze", "factor": 2})
+        elif item == "split":
+            out.append({"type": "split", "non_square": True})
+        else:
+            kind, rev = item
+            out.append({"type": "acl", "mask_type": "checkerboard" if kind == "c" else "split-channel",
+                        "reverse_mask": rev, "num_u_channels": 0,
+                        "coupler": {"independent_nets": False,
+                                    "shift_log_scale_net": {"type": "resnet", "hidden_channels": list(hidden),
+                                                            "batchnorm": False, "ignore_batch_effects": False}}})
+    return out
+
+
+def get_schema(config):
+    """Layer list for a non-square config (reference: ``config.get_schema``,
+    schemas.py:1-27 -> :53-105 apply_non_square_settings -> :30-50 get_preproc_schema)."""
+    if not config.get("non_square", False):
+        raise ValueError("cmf_amd only builds the non-square log-density path")
+    if config["schema_type"] == "flat-realnvp":
+        flow = _flat_realnvp(config["num_density_layers"], config["coupler_hidden_channels"])
+    elif config["schema_type"] == "multiscale-realnvp":
+        flow = _multiscale_realnvp(config["g_hidden_channels"], config.get("smaller_realnvp", False))
+    else:
+        raise ValueError(f"schema_type {config['schema_type']!r} is outside the hot path")
+
+    head = {
+        "type": "non-square-head",
+        "regularization_param": config["regularization_param"],
+        "log_jacobian_method": config["log_jacobian_method"],
+        "hutchinson_distribution": config.get("hutchinson_distribution", "normal"),
+        "hutchinson_samples": config.get("hutchinson_samples", 1),
+        "m_flow": config["m_flow"],
+        "max_cg_iterations": config.get("max_cg_iterations", None),
+        "cg_tolerance": config.get("cg_tolerance", 1),
+        "latent_dimension": config["latent_dimension"],
+        "metric_regularization_param": config["metric_regularization_param"],
+    }
+    tail = [{"type": "non-square-base", "latent_dimension": config["latent_dimension"], "m_flow": config["m_flow"]}]
+    if config["prior"] == "affine":
+        tail.append({"type": "affine", "per_channel": False})
+    elif config["prior"] == "realnvp":
+        tail += _flat_realnvp(config["prior_num_density_layers"], config["prior_hidden_channels"])
+    else:
+        raise ValueError(f"prior {config['prior']!r} is not built (nsf: SURVEY.md f3, parity unpinned)")
+
+    pre = [{"type": "dequantization"}] if config["dequantize"] else []
+    if config.get("logit_tf_lambda") is not None and config.get("logit_tf_scale") is not None:
+        lam, scale = config["logit_tf_lambda"], config["logit_tf_scale"]
+        pre += [{"type": "scalar-mult", "value": (1 - 2 * lam) / scale},
+                {"type": "scalar-add", "value": lam},
+                {"type": "logit"}]
+    return pre + [head] + flow + tail

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference itself.  BUILD CONTAINER ONLY.
+
+Imports k-flouris/cmf from /root/reference (never copied, never shipped), builds each
+BASELINE configuration with the reference's own ``get_config -> get_schema -> get_density``,
+loads the build-owned deterministic weight recipe (``cmf_amd.recipe``) with
+``load_state_dict(strict=True)``, runs the reference's CPU/PyTorch path on seeded synthetic
+inputs and stores inputs + outputs as small fixtures.  The fixtures
+are data (arrays); no reference source text is stored.
+
+The reference's package ``__init__`` files eagerly import un-vendored third-party modules
+(pyro, nsf's ``nde``/``nn``/``utils``, BNAF, gpytorch) that the Cholesky path never
+touches; empty ``sys.modules`` stand-ins for those *names* let the import proceed
+(SURVEY.md section 8c).  Nothing in them is ever called.
+
+Usage:  python oracle/make_golden.py [--only NAME]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _import_reference():
+    class _Unused:
+        def __init__(self, *a, **k):
+            raise RuntimeError("third-party stand-in was called: this path must not reach it")
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    stub("pyro"); stub("pyro.distributions"); stub("pyro.distributions.transforms")
+    stub("pyro.distributions.transforms.polynomial", Polynomial=_Unused)
+    stub("pyro.nn", AutoRegressiveNN=_Unused)
+    stub("nde"); stub("nde.transforms", LULinear=_Unused)
+    stub("nde.transforms.coupling", PiecewiseRationalQuadraticCouplingTransform=_Unused)
+    stub("nde.transforms.autoregressive", MaskedPiecewiseRationalQuadraticAutoregressiveTransform=_Unused)
+    stub("nn", ResidualNet=_Unused); stub("utils", create_alternating_binary_mask=_Unused)
+    stub("BNAF"); stub("BNAF.bnaf", BNAF=_Unused, MaskedWeight=_Unused, Tanh=_Unused)
+    stub("gpytorch"); stub("gpytorch.utils", linear_cg=None)
+    sys.path.insert(0, "/root/reference")
+    from cmf.models import get_density
+    from config import get_config, get_schema, expand_grid
+    return get_density, get_config, get_schema, expand_grid
+
+
+# name -> (dataset, reference-config overrides, batch, extras)
+CASES = {
+    "c1_sphere": ("sphere", {"latent_dimension": 3}, 32),
+    "c1_sphere_d2": ("sphere", {"latent_dimension": 2}, 16),
+    "c2a_power": ("power", {}, 32),
+    "c2b_hepmass": ("hepmass", {}, 16),
+    "mini_mnist": ("mnist", {"g_hidden_channels": [8] * 2, "latent_dimension": 4, "log_jacobian_method": "cholesky"}, 3),
+    "mini_cifar": ("cifar10", {"g_hidden_channels": [8] * 2, "latent_dimension": 6, "log_jacobian_method": "cholesky"}, 2),
+    "mini_mnist_small": ("mnist", {"g_hidden_channels": [8] * 1, "latent_dimension": 5, "smaller_realnvp": True,
+                                   "log_jacobian_method": "cholesky"}, 2),
+    "c3_mnist_full": ("mnist", {"latent_dimension": 64, "log_jacobian_method": "cholesky"}, 2),
+}
+
+ELBO_COMBOS = [  # (likelihood_wt, metric_wt, add_reconstruction, add_offdiag, add_diag)   SURVEY 8(a) a17
+    (1.0, 1.0, True, True, False),
+    (0.0, 0.0, True, True, False),
+    (0.5, 0.5, True, True, False),
+    (1.0, 1.0, False, False, False),
+    (1.0, 2.0, True, False, True),
+]
+
+
+def synth_input(dataset, shape, B, gen):
+    if dataset == "sphere":
+        x = torch.randn(B, *shape, generator=gen)
+        return x / x.norm(dim=1, keepdim=True)
+    if len(shape) == 1:
+        return torch.randn(B, *shape, generator=gen)
+    return torch.randint(0, 256, (B, *shape), generator=gen).float()
+
+
+def find_head(density):
+    m = density
+    while type(m).__name__ != "NonSquareHeadDensity":
+        mods = m._modules
+        m = mods.get("module") or mods.get("density") or mods.get("prior")
+    return m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLDEN, exist_ok=True)
+    get_density, ref_get_config, ref_get_schema, expand_grid = _import_reference()
+    from cmf_amd.recipe import fill_state_dict
+    from cmf_amd import schemas as my_schemas
+
+    for name, (dataset, over, B) in CASES.items():
+        if args.only and args.only != name:
+            continue
+        torch.manual_seed(0)
+        cfg = expand_grid({**ref_get_config(dataset, "non-square", False), **over})[0]
+        schema = ref_get_schema(cfg)
+        # our restated schema builder must produce the identical layer list
+        mine = my_schemas.get_schema(my_schemas.get_config(dataset, **over))
+        assert json.loads(json.dumps(mine)) == json.loads(json.dumps(schema)), f"{name}: schema mismatch"
+
+        shape = my_schemas.DATA_SHAPES[dataset]
+        gen = torch.Generator().manual_seed(1234)
+        x = synth_input(dataset, shape, B, gen)
+        density = get_density(schema, x)
+        sd = fill_state_dict(density.state_dict(), seed=0)
+        # Checkerboard masks with C>1 are stride-0 expanded buffers in the reference (acl.py:73) and
+        # cannot be copied into; they are structural (the recipe leaves them alone), so skip them.
+        res = density.load_state_dict({k: v for k, v in sd.items() if not k.endswith("bijection.mask")}, strict=False)
+        assert not res.unexpected_keys and all(k.endswith("bijection.mask") for k in res.missing_keys)
+        density.eval()
+        out = {"x": x.numpy().copy()}
+        dequant = schema[0]["type"] == "dequantization"
+        noise = torch.rand(x.shape, generator=gen) if dequant else None
+        if dequant:
+            out["noise"] = noise.numpy()
+        head = find_head(density)
+
+        def call_elbo(**kw):
+            xin = x.clone()
+            if dequant:                       # reference draws rand_like(x) from the global RNG first
+                inner = density.module.density          # skip DequantizationDensity, feed x+u ourselves
+                return inner.elbo(xin + noise, **kw)
+            return density.elbo(xin, **kw)
+
+        with torch.no_grad():
+            for i, (lw, mw, rec, off, diag) in enumerate(ELBO_COMBOS):
+                r = call_elbo(likelihood_wt=lw, metric_wt=mw, add_reconstruction=rec,
+                              add_offdiagonal_metric_reg=off, add_diagonal_metric_reg=diag)
+                out[f"elbo_{i}"] = r["elbo"].numpy()
+            # parts, through the reference head's own methods
+            y = x.clone() + noise if dequant else x.clone()
+            pre_lj = torch.zeros(B, 1)
+            m = density.module.density if dequant else density.module
+            while m is not head:
+                res = m.bijection.x_to_z(y)
+                y, pre_lj = res["z"], pre_lj + res["log-jac"]
+                m = m.prior
+            prior_dict = head.prior.elbo(y)
+            z_low, low_elbo, earliest = head._traverse_backward(y, prior_dict)
+            logdet, x_hat, jtj = head._exact_log_det_jac_and_reconstruction(z_low)
+            out.update(head_input=y.numpy(), prehead_logjac=pre_lj.numpy(), z_low=z_low.numpy(),
+                       low_dim_elbo=low_elbo.numpy(), earliest_latent=earliest.numpy(),
+                       logdet=logdet.numpy(), x_hat=x_hat.numpy(), jtj=jtj.numpy())
+            if name != "c3_mnist_full":
+                cols = []
+                for i in range(z_low.shape[1]):
+                    v = torch.zeros_like(z_low); v[:, i] = 1
+                    cols.append(head.jvp_forward(z_low, v)[1].flatten(1))
+                out["J"] = torch.stack(cols, 2).numpy()
+            o = (density.module.density if dequant else density).ood(x.clone() + noise if dequant else x.clone())
+            out["ood_likelihood"] = o["likelihood"].numpy()
+            out["ood_recon"] = o["reconstruction-error"].numpy()
+            xin = x.clone() + noise if dequant else x.clone()
+            inner = density.module.density if dequant else density
+            out["extract_latent"] = inner.extract_latent(xin, earliest_latent=False).numpy()
+            out["extract_earliest"] = inner.extract_latent(xin, earliest_latent=True).numpy()
+            zn = torch.randn(4, cfg["latent_dimension"], generator=gen)
+            out["sample_noise"] = zn.numpy()
+            out["fixed_sample"] = density.fixed_sample(zn).numpy()
+            out["fixed_sample_default"] = density.fixed_sample()[:4].numpy()
+        # Hutchinson building block J^T J eps through the reference's jvp + autograd vjp
+        if name != "c3_mnist_full":
+            S = 3
+            eps = torch.randn(B, cfg["latent_dimension"], S, generator=gen)
+            rep = z_low.repeat_interleave(S, dim=0)
+            vec = eps.transpose(1, 2).reshape(B * S, -1)
+            w, _ = head._jac_transpose_jac_vec(rep, vec, create_graph=False)
+            out["hutch_eps"] = eps.numpy()
+            out["hutch_jtj_eps"] = w.reshape(B, S, -1).transpose(1, 2).detach().numpy()
+            # fp64 reference evaluation of the headline call (tolerance analysis)
+            torch.set_default_dtype(torch.float64)      # the reference allocates with the default dtype
+            try:
+                d64 = get_density(schema, x.double())
+                d64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()
+                                     if not k.endswith("bijection.mask")}, strict=False)
+                d64 = d64.double().eval()
+                with torch.no_grad():
+                    inner64 = d64.module.density if dequant else d64
+                    xin = (x + noise).double() if dequant else x.double()
+                    out["elbo_0_fp64"] = inner64.elbo(xin, add_offdiagonal_metric_reg=True)["elbo"].numpy()
+            finally:
+                torch.set_default_dtype(torch.float32)
+        meta = {"dataset": dataset, "overrides": over, "batch": B, "recipe_seed": 0,
+                "state_dict": {k: [list(v.shape), str(v.dtype)] for k, v in sd.items()},
+                "elbo_combos": ELBO_COMBOS, "cond_jtj_max": float(torch.linalg.cond(jtj).max())}
+        out["meta"] = np.array(json.dumps(meta))
+        path = os.path.join(GOLDEN, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)  cond(JtJ)max={meta['cond_jtj_max']:.3g} "
+              f"elbo0={out['elbo_0'][:2].ravel()}")
+
+
+if __name__ == "__main__":
+    main()

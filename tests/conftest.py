@@ -1,0 +1,73 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Load a fixture written by oracle/make_golden.py -> (arrays dict of torch tensors, meta dict)."""
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    arrs = {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+    return arrs, meta
+
+
+def golden_model(meta, dtype=torch.float32):
+    """Rebuild (schema, x_shape, oracle ops, recipe state dict) for a fixture without the reference:
+    the state-dict key/shape list is stored in the fixture, values come from the recipe."""
+    from cmf_amd import schemas
+    from cmf_amd.recipe import recipe_tensor
+    from oracle import cmf_oracle as O
+
+    cfg = schemas.get_config(meta["dataset"], **meta["overrides"])
+    schema = schemas.get_schema(cfg)
+    x_shape = schemas.DATA_SHAPES[meta["dataset"]]
+    ops = O.compile_schema(schema, x_shape)
+    shapes = {k: tuple(v[0]) for k, v in meta["state_dict"].items()}
+    sd = {}
+    for k, (shape, dt) in meta["state_dict"].items():
+        tdt = getattr(torch, dt.replace("torch.", ""))
+        t = recipe_tensor(k, shape, tdt, meta["recipe_seed"], shapes)
+        if t is None:
+            t = structural_buffer(k, tuple(shape), ops, tdt)
+        if t.is_floating_point():
+            t = t.to(dtype)
+        sd[k] = t.reshape(shape)
+    return cfg, schema, x_shape, ops, sd
+
+
+def structural_buffer(key, shape, ops, dtype):
+    """Constructor-valued buffers the recipe leaves alone: checkerboard masks (acl.py:68-78),
+    tail mask (non_square.py:377), Gaussian mean/stddev (factory.py:196-201)."""
+    from oracle import cmf_oracle as O
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "mean":
+        return torch.zeros(shape, dtype=dtype)
+    if leaf == "stddev":
+        return torch.ones(shape, dtype=dtype)
+    if leaf == "mask" and len(shape) == 1:
+        for op in ops:
+            if op["kind"] == "base" and op["prefix"] + "mask" == key:
+                return torch.arange(shape[0]) < op["d"]
+    if leaf == "mask":
+        for op in ops:
+            if op["kind"] == "acl" and op["prefix"] + "mask" == key:
+                return O.checkerboard_mask(shape, op["reverse"], torch.zeros(1, dtype=dtype))
+    raise KeyError(key)
+
+
+@pytest.fixture(scope="session")
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))

@@ -1,0 +1,130 @@
+"""Pin the CPU oracle (oracle/cmf_oracle.py) against vectors produced by the reference itself
+(oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_model
+from oracle import cmf_oracle as O
+
+SMALL = ["c1_sphere", "c1_sphere_d2", "c2a_power", "c2b_hepmass", "mini_mnist", "mini_cifar", "mini_mnist_small"]
+ALL = SMALL + ["c3_mnist_full"]
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_elbo_and_parts_match_reference(name):
+    g, meta = load_golden(name)
+    cfg, schema, x_shape, ops, sd = golden_model(meta)
+    noise = g.get("noise")
+    with torch.no_grad():
+        for i, (lw, mw, rec, off, diag) in enumerate(meta["elbo_combos"]):
+            if name == "c3_mnist_full" and i not in (0, 1):
+                continue
+            r = O.elbo(sd, ops, g["x"], add_reconstruction=rec, add_offdiagonal_metric_reg=off,
+                       add_diagonal_metric_reg=diag, likelihood_wt=lw, metric_wt=mw, noise=noise, return_parts=(i == 0))
+            assert rel(r["elbo"], g[f"elbo_{i}"]) < 2e-5, (name, i)
+            if i == 0:
+                p = r["parts"]
+                assert rel(p["head_input"], g["head_input"]) < 1e-6
+                assert rel(p["prehead_logjac"], g["prehead_logjac"]) < 1e-6 or g["prehead_logjac"].abs().max() == 0
+                assert rel(p["z_low"], g["z_low"]) < 1e-5
+                assert rel(p["low_dim_elbo"], g["low_dim_elbo"]) < 1e-5
+                assert rel(p["x_hat"], g["x_hat"]) < 1e-5
+                assert rel(p["jtj"], g["jtj"]) < 1e-4
+                assert rel(p["logdet"], g["logdet"]) < 1e-4
+                if "J" in g:
+                    assert rel(p["J"], g["J"]) < 1e-4
+                assert p["attempts"] == 1
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_ref_equivalent_flavour_matches(name):
+    g, meta = load_golden(name)
+    cfg, schema, x_shape, ops, sd = golden_model(meta)
+    with torch.no_grad():
+        r = O.elbo(sd, ops, g["x"], add_offdiagonal_metric_reg=True, noise=g.get("noise"),
+                   flavour="ref_equivalent", return_parts=True)
+    assert rel(r["elbo"], g["elbo_0"]) < 2e-5
+    assert rel(r["parts"]["J"], g["J"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_ood_latents_samples(name):
+    g, meta = load_golden(name)
+    cfg, schema, x_shape, ops, sd = golden_model(meta)
+    noise = g.get("noise")
+    with torch.no_grad():
+        o = O.elbo(sd, ops, g["x"], ood=True, noise=noise)
+        # ood skips the pre-head log-jac: exact.py:45-46 forwards to prior.ood
+        assert rel(o["likelihood"], g["ood_likelihood"]) < 1e-4
+        assert rel(o["reconstruction-error"], g["ood_recon"]) < 1e-4
+        assert rel(O.extract_latent(sd, ops, g["x"], False, noise), g["extract_latent"]) < 1e-5
+        assert rel(O.extract_latent(sd, ops, g["x"], True, noise), g["extract_earliest"]) < 1e-5
+        assert rel(O.fixed_sample(sd, ops, g["sample_noise"]), g["fixed_sample"]) < 1e-4
+        assert rel(O.fixed_sample(sd, ops)[:4], g["fixed_sample_default"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_hutchinson_building_block(name):
+    g, meta = load_golden(name)
+    cfg, schema, x_shape, ops, sd = golden_model(meta)
+    with torch.no_grad():
+        w, _ = O.jtj_matvec(sd, ops, g["z_low"], g["hutch_eps"])
+        assert rel(w, g["hutch_jtj_eps"]) < 1e-4
+        val, _, _ = O.hutchinson_surrogate(sd, ops, g["z_low"], g["hutch_eps"])
+        # exact solve => surrogate value is mean_s ||eps_s||^2  
+        expect = (g["hutch_eps"] ** 2).sum(1, keepdim=True).mean(2)
+        assert rel(val, expect) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["c1_sphere", "c2b_hepmass", "mini_mnist"])
+def test_fp64_oracle_vs_fp64_reference(name):
+    g, meta = load_golden(name)
+    cfg, schema, x_shape, ops, sd = golden_model(meta, dtype=torch.float64)
+    noise = g.get("noise")
+    # the generator dequantises in fp32 (x + u) and then widens: do the same
+    x = g["x"].double() if noise is None else (g["x"] + noise).double()
+    with torch.no_grad():
+        r = O.elbo(sd, ops, x, add_offdiagonal_metric_reg=True, noise=None if noise is None else torch.zeros_like(x))
+    assert rel(r["elbo"], g["elbo_0_fp64"]) < 1e-12
+
+
+def test_known_answers_square_case():
+    """d == D (sphere, d=3): -1/2 logdet(J^T J) == -log|det J|, and the hand-written tangents agree with autograd."""
+    g, meta = load_golden("c1_sphere")
+    cfg, schema, x_shape, ops, sd = golden_model(meta, dtype=torch.float64)
+    pre, head, flow_ops, base, prior_ops = O.split_ops(ops)
+    z = g["z_low"].double()[:4]
+    jtj, xh, J = O.jtj_batched(sd, flow_ops, base, z)
+    logdet, _, _ = O.cholesky_logdet(jtj)
+    assert torch.allclose(logdet.squeeze(1) / 2, torch.linalg.slogdet(J)[1], atol=1e-10)
+    Jad = torch.autograd.functional.jacobian(lambda t: O.flow_forward(sd, flow_ops, base, t[None])[0], z[0])
+    assert torch.allclose(Jad, J[0], atol=1e-10)
+
+
+def test_identity_init_gives_identity_metric():
+    """Zeroed final coupler layers => s = t = 0 => J is a scatter matrix => J^T J = I, logdet 0, l1 0."""
+    g, meta = load_golden("mini_mnist")
+    cfg, schema, x_shape, ops, sd = golden_model(meta)
+    pre, head, flow_ops, base, prior_ops = O.split_ops(ops)
+    for op in flow_ops:
+        if op["kind"] == "acl":
+            p = op["prefix"] + "coupler.shift_log_scale_net."
+            sd[p + "weights"] = torch.zeros_like(sd[p + "weights"])
+            sd[p + "bias"] = torch.zeros_like(sd[p + "bias"])
+    jtj, _, _ = O.jtj_batched(sd, flow_ops, base, g["z_low"])
+    assert torch.allclose(jtj, torch.eye(jtj.shape[1]).expand_as(jtj), atol=1e-6)
+    assert float(O.metric_l1(jtj, False).abs().max()) < 1e-5
+
+
+def test_cholesky_jitter_retry_semantics():
+    """non_square.py:280-288: one non-PD matrix in the batch jitters the WHOLE batch; eps 1e-6 then x10."""
+    G = torch.eye(3).repeat(2, 1, 1)
+    G[1] = torch.tensor([[1., 1., 0.], [1., 1., 0.], [0., 0., 1.]])      # singular
+    logdet, Gj, attempts = O.cholesky_logdet(G)
+    assert attempts >= 2
+    assert torch.allclose(Gj[0], (1 + 1e-6 * sum(10 ** k for k in range(attempts - 1))) * torch.eye(3), atol=1e-7)
