@@ -1,0 +1,85 @@
+"""ctypes binding of libcmf_amd.so (C ABI declared in include/cmf_amd.h).
+
+The product path has no CPU fallback: if the HIP library is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcmf_amd.so")
+
+F_NONE, F_RELU, F_TANH, F_RAW = 0, 1, 2, 3
+O_NONE, O_TANH, O_STANH = 0, 1, 2
+
+_fp = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+_ll = C.c_longlong
+_i = C.c_int
+_f = C.c_float
+
+
+class ConvTangentArgs(C.Structure):
+    _fields_ = [("x", _fp), ("x_np", _ll), ("x_ci", _ll), ("x_px", _ll),
+                ("f", _fp), ("f_np", _ll), ("f_ci", _ll), ("f_px", _ll), ("fmode", _i),
+                ("w", _fp),
+                ("y", _fp), ("y_np", _ll), ("y_co", _ll), ("y_px", _ll),
+                ("r", _fp), ("r_np", _ll), ("r_co", _ll), ("r_px", _ll),
+                ("np", _i), ("cin", _i), ("cout", _i), ("H", _i), ("W", _i), ("nc", _i), ("taps", _i)]
+
+
+class ConvPrimalArgs(C.Structure):
+    _fields_ = [("x", _fp), ("x_b", _ll), ("x_c", _ll), ("x_px", _ll),
+                ("f", _fp), ("f_c", _ll), ("f_px", _ll), ("imode", _i),
+                ("w", _fp), ("bias", _fp), ("sw", _fp), ("sb", _fp),
+                ("y", _fp), ("y_b", _ll), ("y_c", _ll), ("y_px", _ll),
+                ("g", _fp),
+                ("r", _fp), ("r_b", _ll), ("r_c", _ll), ("r_px", _ll),
+                ("omode", _i),
+                ("B", _i), ("cin", _i), ("cout", _i), ("H", _i), ("W", _i), ("taps", _i)]
+
+
+#: every symbol include/cmf_amd.h declares -> (restype, argtypes)
+SIGNATURES = {
+    "cmf_version": (C.c_char_p, []),
+    "cmf_pack_weight": (_i, [_fp, _fp, _i, _i, _i, _i, C.POINTER(_ll), _fp]),
+    "cmf_conv_tangent": (_i, [C.POINTER(ConvTangentArgs), _fp]),
+    "cmf_conv_primal": (_i, [C.POINTER(ConvPrimalArgs), _fp]),
+    "cmf_acl_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
+    "cmf_acl_tangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _fp]),
+    "cmf_gather_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _i, _i, _fp]),
+    "cmf_gather_tangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _fp, _i, _i, _i, _fp]),
+    "cmf_seed_tangent": (_i, [_fp, _ll, _ll, _fp, _i, _i, _fp, _i, _i, _i, _fp]),
+    "cmf_gram_cholesky": (_i, [_fp, _ll, _ll, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "cmf_cholesky_retry": (_i, [_fp, _i, _i, _i, _f, _fp, _fp, _fp, _fp, _fp]),
+    "cmf_prehead": (_i, [_fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _fp]),
+    "cmf_prehead_inverse": (_i, [_fp, _fp, _f, _f, _i, _ll, _fp]),
+    "cmf_gaussian_logprob": (_i, [_fp, _ll, _i, _i, _fp, _fp]),
+    "cmf_affine_prior": (_i, [_fp, _ll, _fp, _fp, _i, _i, _i, _fp, _fp]),
+    "cmf_recon_sqerr": (_i, [_fp, _fp, _i, _i, _fp, _fp]),
+    "cmf_elbo_combine": (_i, [_fp, _fp, _fp, _fp, _fp, _f, _f, _f, _i, _fp, _fp]),
+    "cmf_hutch_value": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcmf_amd.so and bind every declared symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP kernels are the only implementation of this path "
+            "(no CPU fallback). Build them with `python -m cmf_amd.build`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "size out of range"}.get(rc, f"hipError {rc}")
+        raise RuntimeError(f"libcmf_amd: {what} failed: {kind}")

@@ -1,0 +1,362 @@
+"""Bijections on the hot path, with the reference's protocol ``x_to_z / z_to_x / jvp``
+(``cmf/models/components/bijections/bijection.py:7-64``): dict results with keys ``z``/``x``, ``log-jac``
+(B, 1) and ``jvp``, shape asserts on entry and exit.  Arithmetic is done by the HIP kernels
+(``cmf_amd.engine``); each class only contributes its geometry as index maps.
+
+  Checkerboard2dAffineCouplingBijection           acl.py:30-78
+  SplitChannelwiseAffineCouplingBijection         acl.py:169-189
+  AlternatingChannelwiseAffineCouplingBijection   acl.py:192-214
+  ViewBijection / Squeeze2dBijection              reshaping.py:61-114
+  AffineBijection                                 affine.py:10-38
+  LogitBijection / ScalarMultiplication / ScalarAddition   math.py:41-105
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine as E
+
+__all__ = [
+    "Bijection", "AffineCouplingBijection", "Checkerboard2dAffineCouplingBijection",
+    "SplitChannelwiseAffineCouplingBijection", "AlternatingChannelwiseAffineCouplingBijection", "ViewBijection",
+    "Squeeze2dBijection", "AffineBijection", "LogitBijection", "ScalarMultiplicationBijection",
+    "ScalarAdditionBijection",
+]
+
+
+class _DeviceMaps:
+    """int32 index maps, built once on the host and cached per device."""
+
+    def __init__(self):
+        self._host, self._dev = {}, {}
+
+    def put(self, name, arr):
+        self._host[name] = np.ascontiguousarray(arr, dtype=np.int32)
+
+    def get(self, name, device):
+        key = (name, str(device))
+        if key not in self._dev:
+            self._dev[key] = torch.from_numpy(self._host[name]).to(device)
+        return self._dev[key]
+
+
+class Bijection(nn.Module):
+    def __init__(self, x_shape, z_shape):
+        super().__init__()
+        self.x_shape, self.z_shape = tuple(x_shape), tuple(z_shape)
+        self._maps = _DeviceMaps()
+
+    # protocol -------------------------------------------------------------------------------
+    def forward(self, inputs, mode, **kwargs):
+        if mode == "x-to-z":
+            assert inputs.shape[1:] == self.x_shape
+            out = self._x_to_z(inputs, **kwargs)
+            assert out["z"].shape[1:] == self.z_shape
+        elif mode == "z-to-x":
+            assert inputs.shape[1:] == self.z_shape
+            out = self._z_to_x(inputs, **kwargs)
+            assert out["x"].shape[1:] == self.x_shape
+        elif mode == "jvp":
+            v = kwargs.pop("v")
+            assert inputs.shape[1:] == self.z_shape and v.shape[1:] == self.z_shape
+            out = self._jvp(inputs, v, **kwargs)
+            assert out["x"].shape[1:] == self.x_shape and out["jvp"].shape[1:] == self.x_shape
+        else:
+            assert False, f"Invalid mode {mode}"
+        return out
+
+    def x_to_z(self, x, **kwargs):
+        return self(x, "x-to-z", **kwargs)
+
+    def z_to_x(self, z, **kwargs):
+        return self(z, "z-to-x", **kwargs)
+
+    def jvp(self, z, v, **kwargs):
+        return self(z, "jvp", v=v, **kwargs)
+
+    # single-column tangent helpers for the public jvp API -------------------------------------
+    def _wrap_tangent(self, v, layout):
+        B = v.shape[0]
+        N = int(np.prod(v.shape[1:]))
+        ident = torch.arange(N, dtype=torch.int32, device=v.device)
+        eps = v.reshape(B, N, 1).contiguous()            # "probe" form: column 0 carries v
+        return E.seed_tangent(B, N, 16, layout, ident, N, v.device, eps=eps)
+
+    @staticmethod
+    def _unwrap_tangent(T, shape):
+        return T.to_dense(1)[:, :, 0].reshape(T.B, *shape).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+# affine coupling layers
+# --------------------------------------------------------------------------------------------------
+
+
+class AffineCouplingBijection(Bijection):
+    """z = (x + t(x_pass)) * exp(s(x_pass)) on the modified elements; pass-through elsewhere."""
+
+    def __init__(self, x_shape, coupler):
+        super().__init__(x_shape=x_shape, z_shape=x_shape)
+        self.coupler = coupler
+        self.geom = E.Geometry(x_shape)
+
+    @property
+    def net(self):
+        return self.coupler.shift_log_scale_net
+
+    def _set_maps(self, zi, cmod):
+        """zi: flat element ids (in z) of the modified elements, ordered (channel-of-net-output, pixel)."""
+        HW = self.geom.HW
+        n = len(zi)
+        j = np.arange(n)
+        self._maps.put("zi", zi)
+        self._maps.put("ti", j)                 # shift      = first  half of the net's channels (couplers.py:52-59)
+        self._maps.put("si", cmod * HW + j)     # log-scale  = second half
+        self.n_mod, self.cmod = n, cmod
+
+    def maps(self, device):
+        return {"zi": self._maps.get("zi", device), "si": self._maps.get("si", device),
+                "ti": self._maps.get("ti", device), "n": self.n_mod}
+
+    def view(self, device):
+        raise NotImplementedError
+
+    @property
+    def layout(self):
+        return "panel" if self.geom.image else "fmajor"
+
+    # engine-level steps (in place on z / T) ----------------------------------------------------
+    def encode_(self, z, lj=None):
+        y, _, _ = E.net_primal(self.net, z, self.view(z.device))
+        E.acl_primal(z, y, self.maps(z.device), decode=False, lj=lj)
+
+    def decode_(self, z, T=None, lj=None):
+        view = self.view(z.device)
+        y, g, acts = E.net_primal(self.net, z, view)
+        if T is not None:
+            YT = E.net_tangent(self.net, T, view, acts)
+            E.acl_tangent(T, YT, z, y, g, self.maps(z.device))      # uses z BEFORE the primal update
+        E.acl_primal(z, y, self.maps(z.device), decode=True, lj=lj)
+
+    # protocol ------------------------------------------------------------------------------------
+    def _x_to_z(self, x):
+        E.require_gpu(x)
+        z = x.detach().clone().contiguous()
+        lj = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+        self.encode_(z, lj)
+        return {"z": z, "log-jac": lj.view(-1, 1)}
+
+    def _z_to_x(self, z):
+        E.require_gpu(z)
+        x = z.detach().clone().contiguous()
+        lj = torch.zeros(z.shape[0], dtype=torch.float32, device=z.device)
+        self.decode_(x, None, lj)
+        return {"x": x, "log-jac": lj.view(-1, 1)}
+
+    def _jvp(self, z, v):
+        E.require_gpu(z)
+        x = z.detach().clone().contiguous()
+        T = self._wrap_tangent(v.detach(), self.layout)
+        self.decode_(x, T)
+        return {"x": x, "jvp": self._unwrap_tangent(T, self.x_shape)}
+
+
+class Checkerboard2dAffineCouplingBijection(AffineCouplingBijection):
+    def __init__(self, x_shape, coupler, reverse_mask):
+        super().__init__(x_shape=x_shape, coupler=coupler)
+        C, H, W = x_shape
+        ii, jj = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        m = ((ii + jj) % 2 == 1).astype(np.float32)          # 1 = pass-through (acl.py:68-78)
+        if reverse_mask:
+            m = 1 - m
+        mask = np.broadcast_to(m, (C, H, W)).copy()
+        self.register_buffer("mask", torch.from_numpy(mask))
+        self._set_maps(np.flatnonzero(mask.reshape(-1) == 0), cmod=C)
+
+    def view(self, device):
+        return E.NetView(self.geom, cin=self.geom.C, mask=self.mask)
+
+
+class _ChannelwiseACL(AffineCouplingBijection):
+    def __init__(self, x_shape, coupler_factory, pass_idx, mod_idx):
+        coupler = coupler_factory(len(pass_idx))
+        super().__init__(x_shape=x_shape, coupler=coupler)
+        HW = self.geom.HW
+        zi = (np.asarray(mod_idx)[:, None] * HW + np.arange(HW)[None, :]).reshape(-1)
+        self._set_maps(zi, cmod=len(mod_idx))
+        self._pass = (int(pass_idx[0]), int(pass_idx[1] - pass_idx[0]) if len(pass_idx) > 1 else 1, len(pass_idx))
+
+    def view(self, device):
+        off, step, n = self._pass
+        return E.NetView(self.geom, cin=n, chan_off=off, chan_step=step)
+
+
+class SplitChannelwiseAffineCouplingBijection(_ChannelwiseACL):
+    """First half of the channels passes through (second half if reverse_mask): acl.py:169-189."""
+
+    def __init__(self, x_shape, coupler_factory, reverse_mask):
+        C = x_shape[0]
+        first, second = np.arange(0, C // 2), np.arange(C // 2, C)
+        p, m = (second, first) if reverse_mask else (first, second)
+        assert len(p) > 0, "Not a bijection without passthrough"
+        super().__init__(x_shape, coupler_factory, p, m)
+        self.reverse_mask = reverse_mask
+
+
+class AlternatingChannelwiseAffineCouplingBijection(_ChannelwiseACL):
+    """Even channels pass through (odd if reverse_mask): acl.py:192-214."""
+
+    def __init__(self, x_shape, coupler_factory, reverse_mask):
+        C = x_shape[0]
+        first, second = np.arange(0, C, 2), np.arange(1, C, 2)
+        p, m = (second, first) if reverse_mask else (first, second)
+        assert len(p) > 0, "Not a bijection without passthrough"
+        super().__init__(x_shape, coupler_factory, p, m)
+        self.reverse_mask = reverse_mask
+
+
+# --------------------------------------------------------------------------------------------------
+# reshapes
+# --------------------------------------------------------------------------------------------------
+
+
+class _ReshapingBijection(Bijection):
+    """Pure index maps, applied identically to values and tangents (reshaping.py:8-29)."""
+
+    def _index_maps(self):
+        n = int(np.prod(self.x_shape))
+        ids = torch.arange(n).reshape(1, *self.x_shape)
+        self._maps.put("x2z", self._reshape_x(ids).reshape(-1).numpy())    # z[r] = x[x2z[r]]
+        idz = torch.arange(n).reshape(1, *self.z_shape)
+        self._maps.put("z2x", self._reshape_z(idz).reshape(-1).numpy())    # x[r] = z[z2x[r]]
+        self.n = n
+
+    def encode(self, x):
+        return E.gather_primal(x, self._maps.get("x2z", x.device), self.n).view(x.shape[0], *self.z_shape)
+
+    def decode(self, z, T=None):
+        x = E.gather_primal(z, self._maps.get("z2x", z.device), self.n).view(z.shape[0], *self.x_shape)
+        if T is not None:
+            T = E.gather_tangent(T, self._maps.get("z2x", z.device), self.n)
+        return x, T
+
+    def _zeros(self, t):
+        return torch.zeros(t.shape[0], 1, dtype=t.dtype, device=t.device)
+
+    def _x_to_z(self, x):
+        E.require_gpu(x)
+        return {"z": self.encode(x.contiguous()), "log-jac": self._zeros(x)}
+
+    def _z_to_x(self, z):
+        E.require_gpu(z)
+        return {"x": self.decode(z.contiguous())[0], "log-jac": self._zeros(z)}
+
+    def _jvp(self, z, v):
+        E.require_gpu(z)
+        return {"x": self.decode(z.contiguous())[0], "jvp": self.decode(v.contiguous())[0]}
+
+
+class ViewBijection(_ReshapingBijection):
+    def __init__(self, x_shape, z_shape):
+        assert np.prod(x_shape) == np.prod(z_shape)
+        super().__init__(x_shape, z_shape)
+        self.n = int(np.prod(x_shape))
+
+    # a contiguous view: no data movement at all
+    def encode(self, x):
+        return x.view(x.shape[0], *self.z_shape)
+
+    def decode(self, z, T=None):
+        return z.view(z.shape[0], *self.x_shape), T
+
+
+class Squeeze2dBijection(_ReshapingBijection):
+    """Space-to-depth by ``factor`` (reshaping.py:69-114)."""
+
+    def __init__(self, x_shape, factor):
+        C, H, W = x_shape
+        assert H % factor == 0 and W % factor == 0
+        self.factor = factor
+        super().__init__(x_shape, (C * factor * factor, H // factor, W // factor))
+        self._index_maps()
+
+    def _reshape_x(self, x):
+        f, (C, H, W) = self.factor, self.x_shape
+        return x.reshape(-1, C, H // f, f, W // f, f).permute(0, 1, 3, 5, 2, 4).reshape(-1, *self.z_shape)
+
+    def _reshape_z(self, z):
+        f, (C, H, W) = self.factor, self.x_shape
+        return z.reshape(-1, C, f, f, H // f, W // f).permute(0, 1, 4, 2, 5, 3).reshape(-1, *self.x_shape)
+
+
+# --------------------------------------------------------------------------------------------------
+# 2-D prior and pre-head elementwise maps
+# --------------------------------------------------------------------------------------------------
+
+
+class AffineBijection(Bijection):
+    """z = x * exp(log_scale) + shift, per element (affine.py:10-38, per_channel=False)."""
+
+    def __init__(self, x_shape, per_channel=False):
+        assert not per_channel, "only the per-element form is on the non-square path (schemas.py:75-79)"
+        super().__init__(x_shape, x_shape)
+        self.shift = nn.Parameter(torch.zeros(x_shape))
+        self.log_scale = nn.Parameter(torch.zeros(x_shape))
+
+    def encode_(self, z, lj=None):
+        E.affine_prior(z, self.log_scale, self.shift, decode=False, lj=lj)
+
+    def decode_(self, z, lj=None):
+        E.affine_prior(z, self.log_scale, self.shift, decode=True, lj=lj)
+
+    def _x_to_z(self, x):
+        E.require_gpu(x)
+        z, lj = x.detach().clone().contiguous(), torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+        self.encode_(z, lj)
+        return {"z": z, "log-jac": lj.view(-1, 1)}
+
+    def _z_to_x(self, z):
+        E.require_gpu(z)
+        x, lj = z.detach().clone().contiguous(), torch.zeros(z.shape[0], dtype=torch.float32, device=z.device)
+        self.decode_(x, lj)
+        return {"x": x, "log-jac": lj.view(-1, 1)}
+
+
+class _Elementwise(Bijection):
+    """y = a*x + c (optionally followed by logit): the pre-head chain of image configs (math.py:9-105).
+    A run of these in front of the head is fused into one kernel by ``FlowProgram``."""
+    a, c, logit = 1.0, 0.0, False
+
+    def __init__(self, x_shape):
+        super().__init__(x_shape, x_shape)
+
+    def _x_to_z(self, x):
+        E.require_gpu(x)
+        z, lj = E.prehead(x.contiguous(), None, self.a, self.c, self.logit)
+        return {"z": z, "log-jac": lj.view(-1, 1)}
+
+    def _z_to_x(self, z):
+        E.require_gpu(z)
+        x = E.prehead_inverse(z.contiguous(), self.a, self.c, self.logit)
+        lj = -self._x_to_z(x)["log-jac"]
+        return {"x": x, "log-jac": lj}
+
+
+class LogitBijection(_Elementwise):
+    logit = True
+
+
+class ScalarMultiplicationBijection(_Elementwise):
+    def __init__(self, x_shape, value):
+        assert np.isscalar(value) and value != 0., "Scalar multiplication by zero is not a bijection"
+        super().__init__(x_shape)
+        self.value = self.a = float(value)
+
+
+class ScalarAdditionBijection(_Elementwise):
+    def __init__(self, x_shape, value):
+        assert np.isscalar(value)
+        super().__init__(x_shape)
+        self.value = self.c = float(value)

@@ -1,0 +1,304 @@
+// Tangent convolution / linear layer on fp32 MFMA for gfx950 (MI355X).
+//
+// Computes, for all NC Jacobian columns of a sample at once,
+//     y(np, co, px, :) = sum_{ci,tap} W[co][ci][tap] * F(np, ci, px+tap) * x(np, ci, px+tap, :)  [+ r]
+// i.e. the tangent half of the reference's get_conv2d_jvp / get_linear_jvp
+// (cmf/models/components/jvp_layers.py:49-64) for every column of the non-square Jacobian, with the
+// preceding activation's derivative (jvp_layers.py:38-47) applied while the input tile is staged and
+// the residual add of ResidualBlock.jvp (networks.py:62-79) fused into the store.
+//
+// Mapping to the hardware:
+//   * GEMM view per sample: M = cout (A = packed weights), N = (pixel, Jacobian column), K = (tap, cin).
+//     The Jacobian column is the contiguous dimension in HBM, so a B-operand row is one 64-byte
+//     segment and the activation derivative is constant along N: it is a per-K-row scale.
+//   * v_mfma_f32_16x16x4_f32: a wave owns PXW pixels x 16 columns x (COT*16) output channels
+//     = PXW*COT accumulator tiles (4 VGPRs each); 4 waves per workgroup cover a 2 x 2*PXW pixel tile
+//     (3x3) or 4*PXW flat pixels (1x1).  PXW = 7 fits 14- and 28-wide images exactly, 8 fits 16/32.
+//   * K loop in chunks of 8 input channels: the halo tile [8][pix][16] and the weight slab
+//     [taps][8][cout] are staged through LDS; both LDS images are padded so that the two 16-lane
+//     groups of a ds_read_b32 half-wave hit disjoint banks (row stride == 16 mod 32 dwords).
+//   * global -> register prefetch of chunk c+1 is issued before the MFMAs of chunk c and written to
+//     LDS after them (issue-early / write-late), so HBM/L2 latency hides under ~16k MFMA cycles.
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+constexpr int CIC = 8;  // input channels per LDS chunk
+
+template <int TAPS, int COT, int PXW>
+struct Cfg {
+  static constexpr int TW = 2 * PXW;                              // 3x3 tile width
+  static constexpr int TWH = TW + 2;                              // + halo
+  static constexpr int PIXH = (TAPS == 9) ? 4 * TWH : 4 * PXW;    // staged pixels per channel
+  static constexpr int XS_CI = PIXH * 16 + 16;                    // dwords; == 16 (mod 32)
+  static constexpr int WS_CI = (COT % 2) ? COT * 16 : COT * 16 + 16;
+  static constexpr int XS_FLOATS = CIC * XS_CI;
+  static constexpr int WS_FLOATS = TAPS * CIC * WS_CI;
+  static constexpr int NX_ITEMS = CIC * PIXH * 4;                 // float4 items of the X chunk
+  static constexpr int NXIT = (NX_ITEMS + 255) / 256;
+  static constexpr int NW_ITEMS = TAPS * CIC * COT * 4;
+  static constexpr int NWIT = (NW_ITEMS + 255) / 256;
+};
+
+template <int TAPS, int COT, int PXW>
+__global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_args a, int tiles_x, int nslices,
+                                                                int cin_pad) {
+  using C = Cfg<TAPS, COT, PXW>;
+  __shared__ __attribute__((aligned(16))) float smem[C::XS_FLOATS + C::WS_FLOATS];
+  float* Xs = smem;
+  float* Ws = smem + C::XS_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, cl = lane & 15;
+
+  const int tile = blockIdx.x;
+  const int slice = blockIdx.y % nslices;
+  const int cog = blockIdx.y / nslices;
+  const int np = blockIdx.z;
+  const int HW = a.H * a.W;
+
+  int y0 = 0, x0 = 0, p0 = 0;
+  if (TAPS == 9) {
+    y0 = 2 * (tile / tiles_x);
+    x0 = C::TW * (tile % tiles_x);
+  } else {
+    p0 = tile * 4 * PXW;
+  }
+
+  const float* xb = a.x + (long long)np * a.x_np + slice * 16;
+  const float* fb = a.f ? a.f + (long long)np * a.f_np : nullptr;
+  const float* wb = a.w + (long long)cog * TAPS * cin_pad * 64;  // one co-group slab: < 2^31 floats
+
+  // ---- per-thread staging plan (chunk independent part) ----
+  // Every global load below is UNCONDITIONAL (invalid items read element 0 and are zeroed by their
+  // factor at commit time): a conditional load makes hipcc branch and drain vmcnt per item.
+  const int x_ci = (int)a.x_ci, x_px = (int)a.x_px, f_ci = (int)a.f_ci, f_px = (int)a.f_px;
+  int xo[C::NXIT], fo[C::NXIT];
+  unsigned okbits = 0;
+#pragma unroll
+  for (int it = 0; it < C::NXIT; ++it) {
+    const int i = tid + 256 * it;
+    const int q = i & 3, rowi = i >> 2;
+    const int pix = rowi % C::PIXH, ci = rowi / C::PIXH;
+    bool ok = i < C::NX_ITEMS;
+    int gpix;
+    if (TAPS == 9) {
+      const int hy = pix / C::TWH, hx = pix % C::TWH;
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      gpix = gy * a.W + gx;
+    } else {
+      gpix = p0 + pix;
+      ok = ok && gpix < HW;
+    }
+    xo[it] = ok ? ci * x_ci + gpix * x_px + q * 4 : 0;
+    fo[it] = ok ? ci * f_ci + gpix * f_px : 0;
+    okbits |= (ok ? 1u : 0u) << it;
+  }
+
+  f32x4 xr[C::NXIT];
+  float fr[C::NXIT];
+  f32x4 wr[C::NWIT];
+  const float fzero = (a.fmode == CMF_F_TANH) ? 1.f : 0.f;   // factor source value that yields multiplier 0
+
+  auto prefetch = [&](int ci0) {
+#pragma unroll
+    for (int it = 0; it < C::NXIT; ++it) {
+      const int ci = ((tid + 256 * it) >> 2) / C::PIXH;
+      const bool ok = ((okbits >> it) & 1u) && (ci0 + ci) < a.cin;
+      xr[it] = *reinterpret_cast<const f32x4*>(xb + (ok ? ci0 * x_ci + xo[it] : 0));
+      if (a.fmode != CMF_F_NONE) {
+        const float fv = fb[ok ? ci0 * f_ci + fo[it] : 0];
+        fr[it] = ok ? fv : fzero;
+      } else {
+        fr[it] = ok ? 1.f : 0.f;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < C::NWIT; ++it) {
+      int i = tid + 256 * it;
+      i = i < C::NW_ITEMS ? i : C::NW_ITEMS - 1;
+      const int q = i % (COT * 4), rowi = i / (COT * 4);
+      const int ci = rowi % CIC, tap = rowi / CIC;
+      wr[it] = *reinterpret_cast<const f32x4*>(wb + (tap * cin_pad + ci0 + ci) * 64 + q * 4);
+    }
+  };
+
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < C::NXIT; ++it) {
+      const int i = tid + 256 * it;
+      if (i < C::NX_ITEMS) {
+        const int q = i & 3, rowi = i >> 2;
+        const int pix = rowi % C::PIXH, ci = rowi / C::PIXH;
+        float m = fr[it];
+        if (a.fmode == CMF_F_RELU) m = m > 0.f ? 1.f : 0.f;
+        else if (a.fmode == CMF_F_TANH) m = 1.f - m * m;
+        *reinterpret_cast<f32x4*>(Xs + ci * C::XS_CI + pix * 16 + q * 4) = xr[it] * m;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < C::NWIT; ++it) {
+      const int i = tid + 256 * it;
+      if (i < C::NW_ITEMS) {
+        const int q = i % (COT * 4), rowi = i / (COT * 4);
+        *reinterpret_cast<f32x4*>(Ws + rowi * C::WS_CI + q * 4) = wr[it];
+      }
+    }
+  };
+
+  // ---- accumulators ----
+  f32x4 acc[PXW][COT];
+#pragma unroll
+  for (int p = 0; p < PXW; ++p)
+#pragma unroll
+    for (int c = 0; c < COT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wrow = wave >> 1, wx = (wave & 1) * PXW;
+  const float* a_base = Ws + kq * C::WS_CI + cl;
+  const float* b_base =
+      Xs + kq * C::XS_CI + cl + ((TAPS == 9) ? (wrow * C::TWH + wx) * 16 : (wave * PXW) * 16);
+
+  const int nchunks = (a.cin + CIC - 1) / CIC;
+  prefetch(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    commit();
+    __syncthreads();
+    if (ch + 1 < nchunks) prefetch((ch + 1) * CIC);
+
+#pragma unroll
+    for (int kg = 0; kg < CIC / 4; ++kg) {
+      if (TAPS == 9) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          float brow[PXW + 2];
+#pragma unroll
+          for (int j = 0; j < PXW + 2; ++j) brow[j] = b_base[kg * 4 * C::XS_CI + (dy * C::TWH + j) * 16];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            float av[COT];
+#pragma unroll
+            for (int c = 0; c < COT; ++c) av[c] = a_base[((dy * 3 + dx) * CIC + kg * 4) * C::WS_CI + c * 16];
+#pragma unroll
+            for (int p = 0; p < PXW; ++p)
+#pragma unroll
+              for (int c = 0; c < COT; ++c)
+                acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], brow[p + dx], acc[p][c], 0, 0, 0);
+          }
+        }
+      } else {
+        float av[COT];
+#pragma unroll
+        for (int c = 0; c < COT; ++c) av[c] = a_base[(kg * 4) * C::WS_CI + c * 16];
+#pragma unroll
+        for (int p = 0; p < PXW; ++p) {
+          const float bv = b_base[kg * 4 * C::XS_CI + p * 16];
+#pragma unroll
+          for (int c = 0; c < COT; ++c)
+            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv, acc[p][c], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[row = kq*4 + r][col = cl] of tile (p, c); offsets fit 32 bits (host-checked) ----
+  const int y_co = (int)a.y_co, y_px = (int)a.y_px, r_co = (int)a.r_co, r_px = (int)a.r_px;
+  float* ybase = a.y + (long long)np * a.y_np + slice * 16 + cl;
+  const float* rbase = a.r ? a.r + (long long)np * a.r_np + slice * 16 + cl : nullptr;
+  const int co0 = cog * 64 + kq * 4;
+  const bool full = (cog * 64 + COT * 16) <= a.cout;   // uniform: no per-channel bound checks needed
+
+  auto store_all = [&](auto has_res, auto is_full) {
+#pragma unroll
+    for (int p = 0; p < PXW; ++p) {
+      int gpix;
+      bool ok;
+      if (TAPS == 9) {
+        const int gy = y0 + wrow, gx = x0 + wx + p;
+        ok = gy < a.H && gx < a.W;
+        gpix = gy * a.W + gx;
+      } else {
+        gpix = p0 + wave * PXW + p;
+        ok = gpix < HW;
+      }
+      if (!ok) continue;                                  // wave-uniform
+      float* yp = ybase + gpix * y_px + co0 * y_co;
+      const float* rp = has_res ? rbase + gpix * r_px + co0 * r_co : nullptr;
+#pragma unroll
+      for (int c = 0; c < COT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (is_full || (co0 + c * 16 + r) < a.cout) {
+            float v = acc[p][c][r];
+            if (has_res) v += rp[(c * 16 + r) * r_co];
+            yp[(c * 16 + r) * y_co] = v;
+          }
+        }
+    }
+  };
+  if (rbase) {
+    if (full) store_all(std::true_type{}, std::true_type{});
+    else store_all(std::true_type{}, std::false_type{});
+  } else {
+    if (full) store_all(std::false_type{}, std::true_type{});
+    else store_all(std::false_type{}, std::false_type{});
+  }
+}
+
+template <int TAPS, int COT, int PXW>
+int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
+  const int HW = a.H * a.W;
+  int tiles, tiles_x = 1;
+  if (TAPS == 9) {
+    tiles_x = cmf_ceil_div(a.W, 2 * PXW);
+    tiles = tiles_x * cmf_ceil_div(a.H, 2);
+  } else {
+    tiles = cmf_ceil_div(HW, 4 * PXW);
+  }
+  const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
+  const int cin_pad = (a.cin + 7) / 8 * 8;
+  dim3 grid(tiles, nslices * ncog, a.np);
+  hipLaunchKernelGGL((conv_tangent_kernel<TAPS, COT, PXW>), grid, dim3(256), 0, s, a, tiles_x, nslices, cin_pad);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int TAPS, int PXW>
+int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
+  const int cot = (a.cout >= 64) ? 4 : (a.cout + 15) / 16;
+  switch (cot) {
+    case 1: return launch<TAPS, 1, PXW>(a, s);
+    case 2: return launch<TAPS, 2, PXW>(a, s);
+    case 3: return launch<TAPS, 3, PXW>(a, s);
+    default: return launch<TAPS, 4, PXW>(a, s);
+  }
+}
+
+inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 31); }
+
+}  // namespace
+
+extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
+  if (!ap) return CMF_EINVAL;
+  const cmf_conv_tangent_args& a = *ap;
+  if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
+  if (a.taps != 1 && a.taps != 9) return CMF_EINVAL;
+  if (a.nc <= 0 || a.nc % 16) return CMF_EINVAL;
+  if (a.fmode < CMF_F_NONE || a.fmode > CMF_F_RAW || (a.fmode != CMF_F_NONE && !a.f)) return CMF_EINVAL;
+  // 16-byte vector loads of the column slices
+  if ((a.x_np | a.x_ci | a.x_px) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
+  const long long HW = (long long)a.H * a.W;
+  // per-sample offsets are held in 32-bit registers
+  if (!fits_int((a.cin + 8) * a.x_ci + HW * a.x_px + a.nc) || !fits_int((a.cin + 8) * a.f_ci + HW * a.f_px) ||
+      !fits_int((a.cout + 64) * a.y_co + HW * a.y_px + a.nc) || (a.r && !fits_int((a.cout + 64) * a.r_co + HW * a.r_px + a.nc)) ||
+      a.np > 65535 || HW > (1 << 24))
+    return CMF_ERANGE;
+  hipStream_t s = (hipStream_t)stream;
+  const bool seven = (a.taps == 9) ? (a.W % 14 == 0) : (HW % 28 == 0 && HW % 32 != 0);
+  if (a.taps == 9) return seven ? launch_cot<9, 7>(a, s) : launch_cot<9, 8>(a, s);
+  return seven ? launch_cot<1, 7>(a, s) : launch_cot<1, 8>(a, s);
+}

@@ -1,0 +1,576 @@
+"""Density modules with the reference's API (``cmf/models/components/densities``): mode-dispatch
+``forward`` and ``elbo / sample / fixed_sample / jvp / ood / extract_latent`` with the same kwargs
+and result-dict keys, the same nesting (``.prior`` / ``.density`` / ``.density_1`` / ``.module``)
+and therefore the same state-dict key schema.
+
+What differs is how the non-square head evaluates its log-density.  The reference's
+``NonSquareHeadDensity._elbo`` (non_square.py:64-129) re-walks the module chain on every call,
+builds two stacks of bound methods (:146-188) and pushes ONE Jacobian column per decode of the whole
+stack (:298-311).  Here the chain is compiled once into a ``FlowProgram`` that keeps the primal in
+the reference's (B, C, H, W) layout and carries ALL d Jacobian columns of a sample side by side
+(column-innermost tangent tensors), so each coupler-network layer is a single MFMA kernel launch
+for the whole batch and all columns, followed by the fused Gram + Cholesky + log-det kernel.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .bijections import AffineBijection, AffineCouplingBijection, _Elementwise, _ReshapingBijection
+
+__all__ = ["Density", "BijectionDensity", "SplitDensity", "DiagonalGaussianDensity", "WrapperDensity",
+           "DequantizationDensity", "DataParallelDensity", "NonSquareHeadDensity", "ManifoldFlowHeadDensity",
+           "NonSquareTailDensity", "FlowProgram"]
+
+
+class Density(nn.Module):
+    """Mode-string dispatch kept from the reference (density.py:7-28)."""
+
+    def forward(self, mode, *args, **kwargs):
+        if mode == "elbo":
+            return self._elbo(*args, **kwargs)
+        if mode == "sample":
+            return self._sample(*args)
+        if mode == "fixed-sample":
+            return self._fixed_sample(*args)
+        if mode == "jvp":
+            return self._jvp(*args)
+        if mode == "ood":
+            return self._ood(*args)
+        if mode == "extract-latent":
+            return self._extract_latent(*args, **kwargs)
+        assert False, f"Invalid mode {mode}"
+
+    def elbo(self, x, **kwargs):
+        return self("elbo", x, **kwargs)
+
+    def sample(self, num_samples):
+        return self("sample", num_samples)
+
+    def fixed_sample(self, noise=None):
+        return self("fixed-sample", noise)
+
+    def jvp(self, x, v):
+        return self("jvp", x, v)
+
+    def ood(self, x):
+        return self("ood", x)
+
+    def extract_latent(self, x, **kwargs):
+        return self("extract-latent", x, **kwargs)
+
+    def _elbo(self, x, **kwargs):
+        raise NotImplementedError
+
+    def _sample(self, num_samples):
+        raise NotImplementedError
+
+    def _fixed_sample(self, noise):
+        raise NotImplementedError
+
+    def _jvp(self, x, v):
+        raise NotImplementedError
+
+    def _ood(self, x):
+        raise NotImplementedError
+
+    def _extract_latent(self, x, **kwargs):
+        raise NotImplementedError
+
+
+class BijectionDensity(Density):
+    """p(x) = prior(f(x)) |det df/dx|   (exact.py:8-47)."""
+
+    def __init__(self, prior, bijection):
+        super().__init__()
+        self.bijection = bijection
+        self.prior = prior
+
+    def _fused_prehead(self):
+        """A run of elementwise bijections ending at the non-square head is one kernel:
+        y = a*x + c [-> logit] and one log-jacobian, handed to the head (exact.py:23-30 unrolled)."""
+        a, c, logit, node = 1.0, 0.0, False, self
+        while isinstance(node, BijectionDensity) and isinstance(node.bijection, _Elementwise):
+            if logit:
+                return None                       # something follows a logit: not the image pre-processing chain
+            bj = node.bijection
+            a, c, logit = a * bj.a, c * bj.a + bj.c, bj.logit
+            node = node.prior
+        return (a, c, logit, node) if isinstance(node, NonSquareHeadDensity) else None
+
+    def _elbo(self, x, **kwargs):
+        fused = self._fused_prehead() if x.is_cuda else None
+        if fused is not None:
+            a, c, logit, head = fused
+            E.require_gpu(x)
+            y, lj = E.prehead(x.contiguous(), None, a, c, logit)
+            return head.elbo(y, _pre_logjac=lj, **kwargs)
+        result = self.bijection.x_to_z(x)
+        prior_dict = self.prior.elbo(result["z"], **kwargs)
+        return {"elbo": prior_dict["elbo"] + result["log-jac"], "bijection-info": result, "prior-dict": prior_dict}
+
+    def _sample(self, num_samples):
+        return self.bijection.z_to_x(self.prior.sample(num_samples))["x"]
+
+    def _fixed_sample(self, noise):
+        return self.bijection.z_to_x(self.prior.fixed_sample(noise=noise))["x"]
+
+    def _extract_latent(self, x, **kwargs):
+        return self.prior.extract_latent(self.bijection.x_to_z(x)["z"], **kwargs)
+
+    def _jvp(self, x, v):
+        return self.bijection.jvp(x, v)
+
+    def _ood(self, x):
+        return self.prior.ood(self.bijection.x_to_z(x)["z"])
+
+
+class SplitDensity(Density):
+    """Multi-scale split: first half of the channels continues, second half is N(0, I)
+    (split.py:6-52).  In non-square models the dropped half is zero-padded on the way back."""
+
+    def __init__(self, density_1, density_2, dim, non_square=False):
+        super().__init__()
+        self.density_1, self.density_2, self.dim, self.non_square = density_1, density_2, dim, non_square
+
+    def _elbo(self, x):
+        x1, x2 = torch.chunk(x, chunks=2, dim=self.dim)
+        d1, d2 = self.density_1.elbo(x1.contiguous()), self.density_2.elbo(x2.contiguous())
+        return {"elbo": d1["elbo"] + d2["elbo"], "prior-dict": d1, "prior-dict-2": d2}
+
+    def pad_inputs(self, x1):
+        return {"x": torch.cat((x1, torch.zeros_like(x1)), dim=self.dim)}
+
+    def _jvp(self, x, v):
+        return {"x": self.pad_inputs(x)["x"], "jvp": self.pad_inputs(v)["x"]}
+
+    def _fixed_sample(self, noise):
+        x1 = self.density_1.fixed_sample(noise=noise)
+        if self.non_square:
+            return self.pad_inputs(x1)["x"]
+        return torch.cat((x1, self.density_2.fixed_sample(noise=noise)), dim=self.dim)
+
+    def _sample(self, num_samples):
+        x1 = self.density_1.sample(num_samples)
+        if self.non_square:
+            return self.pad_inputs(x1)["x"]
+        return torch.cat((x1, self.density_2.sample(num_samples)), dim=self.dim)
+
+
+class DiagonalGaussianDensity(Density):
+    """Standard normal base density (gaussian.py:44-97 with the mean 0 / stddev 1 buffers of
+    factory.py:196-201).  Non-unit buffers are honoured by whitening on the host side."""
+
+    def __init__(self, mean, stddev, num_fixed_samples=0):
+        super().__init__()
+        assert mean.shape == stddev.shape
+        self.register_buffer("mean", mean)
+        self.register_buffer("stddev", stddev)
+        if num_fixed_samples > 0:
+            self.register_buffer("_fixed_samples", self._draw(num_fixed_samples))
+
+    @property
+    def shape(self):
+        return self.mean.shape
+
+    def _draw(self, n):
+        eps = torch.randn(n, *self.shape, device=self.mean.device)
+        return self.stddev * eps + self.mean
+
+    def logprob_accumulate(self, z, lp):
+        """lp[b] += log N(z_b; mean, stddev^2) via the HIP reduction."""
+        w = (z - self.mean) / self.stddev if self._nonstandard() else z
+        E.gaussian_logprob(w.contiguous(), lp)
+        if self._nonstandard():
+            lp -= torch.log(self.stddev).sum()
+
+    def _nonstandard(self):
+        key = (self.mean._version, self.stddev._version, self.mean.data_ptr())
+        if getattr(self, "_ns_cache", (None, None))[0] != key:      # one device read per (re)load, not per call
+            self._ns_cache = (key, bool((self.mean != 0).any() or (self.stddev != 1).any()))
+        return self._ns_cache[1]
+
+    def _elbo(self, z):
+        E.require_gpu(z)
+        lp = torch.zeros(z.shape[0], dtype=torch.float32, device=z.device)
+        self.logprob_accumulate(z, lp)
+        return {"elbo": lp.view(-1, 1), "z": z}
+
+    def _sample(self, num_samples):
+        return self._draw(num_samples)
+
+    def _fixed_sample(self, noise):
+        return noise if noise is not None else self._fixed_samples
+
+    def _extract_latent(self, x, **kwargs):
+        return x
+
+
+class WrapperDensity(Density):
+    def __init__(self, density):
+        super().__init__()
+        self.density = density
+
+    def _elbo(self, x, **kwargs):
+        return self.density.elbo(x, **kwargs)
+
+    def _sample(self, num_samples):
+        return self.density.sample(num_samples)
+
+    def _fixed_sample(self, noise):
+        return self.density.fixed_sample(noise=noise)
+
+    def _ood(self, x):
+        return self.density.ood(x)
+
+    def _extract_latent(self, x, **kwargs):
+        return self.density.extract_latent(x, **kwargs)
+
+
+class DequantizationDensity(WrapperDensity):
+    """Adds U[0,1) noise IN PLACE to the caller's tensor, exactly like wrapper.py:28-30."""
+
+    def _elbo(self, x, **kwargs):
+        return super()._elbo(x.add_(torch.rand_like(x)), **kwargs)
+
+
+class DataParallelDensity(nn.Module):
+    """Keeps the ``module.`` state-dict prefix of the reference's ``nn.DataParallel`` wrapper
+    (wrapper.py:52-68, factory.py:76-81).  Scaling itself is one process per GPU
+    (``cmf_amd.distributed``), so this wrapper only forwards."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def elbo(self, x, **kwargs):
+        return self("elbo", x, **kwargs)
+
+    def ood(self, x):
+        return self("ood", x)
+
+    def extract_latent(self, x, **kwargs):
+        return self("extract-latent", x, **kwargs)
+
+    def sample(self, num_samples):
+        return self.module.sample(num_samples)
+
+    def fixed_sample(self, noise=None):
+        return self.module.fixed_sample(noise=noise)
+
+
+# --------------------------------------------------------------------------------------------------
+# the compiled chain between head and base
+# --------------------------------------------------------------------------------------------------
+
+
+class FlowProgram:
+    """Static plan of the layers between a NonSquareHeadDensity and the Gaussian at the bottom of its
+    low-dimensional prior; replaces ``_traverse_backward`` / ``_set_flow_and_jvp_stacks``
+    (non_square.py:146-188), which the reference rebuilds on every call."""
+
+    #: bytes of tangent activations one sub-batch may occupy (three hidden panels + J + net output)
+    TANGENT_BUDGET = 64 << 30
+
+    def __init__(self, head):
+        self.layers = []
+        node = head.prior
+        while not isinstance(node, NonSquareTailDensity):
+            if isinstance(node, BijectionDensity):
+                self.layers.append(node.bijection)
+                node = node.prior
+            elif isinstance(node, SplitDensity):
+                self.layers.append(node)
+                node = node.density_1
+            else:
+                raise ValueError(f"Cannot handle density of class {type(node).__name__}")   # non_square.py:168
+        self.tail = node
+        self.prior = []
+        node = node.prior
+        while isinstance(node, BijectionDensity):
+            self.prior.append(node.bijection)
+            node = node.prior
+        if not isinstance(node, DiagonalGaussianDensity):
+            raise ValueError(f"low-dimensional prior must end in a DiagonalGaussianDensity, got {type(node).__name__}")
+        self.gaussian = node
+        self.d = self.tail.latent_dimension
+        self.image = len(self.tail.x_shape) == 3
+        self.layout = "panel" if self.image else "fmajor"
+        for m in self.layers:
+            if isinstance(m, AffineCouplingBijection) and m.geom.image != self.image:
+                raise NotImplementedError("mixed image / flat coupling stacks between head and base are not built")
+        for m in self.prior:
+            if not isinstance(m, (AffineCouplingBijection, AffineBijection, _ReshapingBijection)):
+                raise NotImplementedError(f"prior layer {type(m).__name__} is outside the hot path (nsf: SURVEY f3)")
+
+    # -- per-sample tangent footprint, for sub-batching ------------------------------------------
+    def tangent_bytes_per_sample(self, nc):
+        worst = 0
+        for m in self.layers:
+            if isinstance(m, AffineCouplingBijection):
+                net = m.net
+                if net.kind == "resnet":
+                    hid = net.module[0].out_channels
+                    worst = max(worst, (3 * hid + 2 * m.cmod) * m.geom.HW)
+                else:
+                    worst = max(worst, 3 * max(l.out_features for l in net if isinstance(l, nn.Linear)))
+        D = int(np.prod(self.tail.x_shape))
+        return 4 * nc * (worst + 4 * D)
+
+    # -- x -> (z_low, low_dim_elbo, earliest latent) ----------------------------------------------
+    def encode(self, x):
+        B = x.shape[0]
+        h = x.detach().clone().contiguous()
+        for m in self.layers:
+            if isinstance(m, AffineCouplingBijection):
+                m.encode_(h)                     # log-jac above the base is discarded: non_square.py:157-158,177
+            elif isinstance(m, SplitDensity):
+                n = h[0].numel() // 2            # keep channel half 1 (split.py:16-17)
+                idx = torch.arange(n, dtype=torch.int32, device=h.device)
+                h = E.gather_primal(h, idx, n).view(B, h.shape[1] // 2, *h.shape[2:])
+            else:
+                h = m.encode(h)
+        z_low = E.gather_primal(h, self.tail.gather_index(h.device), self.d)
+        u = z_low.clone()
+        lj = torch.zeros(B, dtype=torch.float32, device=x.device)
+        for m in self.prior:
+            if isinstance(m, (AffineCouplingBijection, AffineBijection)):
+                m.encode_(u, lj)
+        self.gaussian.logprob_accumulate(u, lj)
+        return z_low, lj, u
+
+    # -- z_low -> (x_hat, J) ----------------------------------------------------------------------
+    def decode(self, z_low, tangents=True, eps=None):
+        B, dev = z_low.shape[0], z_low.device
+        N = int(np.prod(self.tail.x_shape))
+        scatter = self.tail.scatter_index(dev)
+        z = E.gather_primal(z_low.contiguous(), scatter, N).view(B, *self.tail.x_shape)
+        T = None
+        if tangents:
+            ncols = self.d if eps is None else eps.shape[2]
+            T = E.seed_tangent(B, N, E.ceil16(ncols), self.layout, scatter, self.d, dev, eps=eps)
+        for m in reversed(self.layers):
+            if isinstance(m, AffineCouplingBijection):
+                m.decode_(z, T)
+            elif isinstance(m, SplitDensity):
+                n = z[0].numel()                 # zero-pad the dropped half (split.py:50-52)
+                idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),
+                                 torch.full((n,), -1, dtype=torch.int32, device=dev)))
+                z = E.gather_primal(z, idx, 2 * n).view(B, 2 * z.shape[1], *z.shape[2:])
+                if T is not None:
+                    T = E.gather_tangent(T, idx, 2 * n)
+            else:
+                z, T = m.decode(z, T)
+        return z, T
+
+    # -- latent noise -> z_low (sampling) ----------------------------------------------------------
+    def prior_inverse(self, u):
+        z = u.detach().clone().contiguous()
+        for m in reversed(self.prior):
+            if isinstance(m, (AffineCouplingBijection, AffineBijection)):
+                m.decode_(z)
+        return z
+
+
+class NonSquareTailDensity(Density):
+    """Bottom of the non-square stack: flatten, fixed random permutation, keep the first d
+    coordinates (non_square.py:367-421).  The permutation is drawn at construction and saved in
+    checkpoints, like the reference's ``randperm`` buffer (:378)."""
+
+    def __init__(self, prior, x_shape, latent_dimension, detach_before_prior):
+        super().__init__()
+        self.prior = prior
+        self.detach_before_prior = detach_before_prior
+        self.x_shape = tuple(x_shape)
+        self.latent_dimension = latent_dimension
+        self.flattened_dims = int(np.prod(x_shape))
+        self.register_buffer("mask", torch.arange(self.flattened_dims) < latent_dimension)
+        self.register_buffer("permutation", torch.randperm(self.flattened_dims))
+        self.register_buffer("inverse_permutation", torch.argsort(self.permutation))
+
+    def gather_index(self, device):
+        return self.permutation[: self.latent_dimension].to(device=device, dtype=torch.int32).contiguous()
+
+    def scatter_index(self, device):
+        inv = self.inverse_permutation.to(device)
+        return torch.where(inv < self.latent_dimension, inv, torch.full_like(inv, -1)).to(torch.int32).contiguous()
+
+    def _elbo(self, x):
+        E.require_gpu(x)
+        low = E.gather_primal(x.contiguous(), self.gather_index(x.device), self.latent_dimension)
+        prior_dict = self.prior.elbo(low.detach() if self.detach_before_prior else low)
+        return {"elbo": prior_dict["elbo"], "low-dim-x": low, "prior-dict": prior_dict}
+
+    def low_dim_to_masked(self, low_dim_x):
+        E.require_gpu(low_dim_x)
+        out = E.gather_primal(low_dim_x.contiguous(), self.scatter_index(low_dim_x.device), self.flattened_dims)
+        return {"x": out.view(low_dim_x.shape[0], *self.x_shape)}
+
+    def _jvp(self, x, v):
+        return {"x": self.low_dim_to_masked(x)["x"], "jvp": self.low_dim_to_masked(v)["x"]}
+
+    def _fixed_sample(self, noise):
+        return self.low_dim_to_masked(self.prior.fixed_sample(noise))["x"]
+
+    def _sample(self, num_samples):
+        return self.low_dim_to_masked(self.prior.sample(num_samples))["x"]
+
+    def _extract_latent(self, x, **kwargs):
+        return self.prior.extract_latent(x, **kwargs)
+
+
+class NonSquareHeadDensity(Density):
+    """log p(x) ~ log p_Z(z) - 1/2 log det(J^T J) - lambda ||x_hat - x||^2 - w_M * g-term
+    (non_square.py:22-129), J the Jacobian of the decoder z -> x_hat at z = encode(x)."""
+
+    _VALID_LOG_JACOBIAN_METHODS = ["cholesky", "hutch_with_cg"]
+    MAX_ATTEMPTS = 6        # the reference declares it (non_square.py:265) but loops forever; we stop here
+    _jacobian_free = False   # M-flow baseline: likelihood term without the log-det (non_square.py:341-346)
+    check_cholesky = "sync"  # "sync": read the retry flags after each call (warn / raise like the reference);
+    #                          "lazy": never synchronise; attempts are left in ``last_gram.fail`` on the device
+
+    def __init__(self, prior, regularization_param, log_jacobian_method, x_shape, hutchinson_distribution,
+                 num_hutchinson_samples=1, max_cg_iterations=None, cg_tolerance=1):
+        super().__init__()
+        self.prior = prior
+        self.regularization_param = regularization_param
+        self.x_shape = tuple(x_shape)
+        self.hutchinson_distribution = hutchinson_distribution
+        self.num_hutchinson_samples = num_hutchinson_samples
+        self.max_cg_iterations = max_cg_iterations
+        self.cg_tolerance = cg_tolerance
+        if log_jacobian_method not in self._VALID_LOG_JACOBIAN_METHODS:
+            raise ValueError(f"{log_jacobian_method} not a valid Jacobian calculation method")
+        self.log_jacobian_method = log_jacobian_method
+        self._program = None
+        self.last_gram = None
+
+    @property
+    def program(self):
+        if self._program is None:
+            self._program = FlowProgram(self)
+        return self._program
+
+    # ------------------------------------------------------------------------------------------
+    def _check_grad(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError(
+                "cmf_amd: the HIP log-density path is forward-only in this build (reverse-mode kernels are the "
+                "next scope row, SURVEY.md f1); call it under torch.no_grad()")
+
+    def _elbo(self, x, add_reconstruction=True, add_diagonal_metric_reg=False, add_offdiagonal_metric_reg=False,
+              likelihood_wt=1., metric_wt=1., visualization=False, ood=False, test_metric=False, _pre_logjac=None):
+        E.require_gpu(x)
+        self._check_grad()
+        if ood:
+            assert self.log_jacobian_method == "cholesky"
+        if add_reconstruction:
+            assert not visualization
+        prog = self.program
+        B = x.shape[0]
+        want_lik = not np.isclose(likelihood_wt, 0.)
+        want_jac = want_lik and not (self._jacobian_free and not (visualization or ood))
+        if ood:
+            assert add_reconstruction and want_lik
+        chunk = B
+        if want_jac:
+            per = prog.tangent_bytes_per_sample(E.ceil16(prog.d))
+            chunk = max(1, min(B, prog.TANGENT_BUDGET // max(per, 1)))
+        outs = [self._elbo_chunk(x[i:i + chunk], want_lik, want_jac, add_reconstruction, add_diagonal_metric_reg,
+                                 add_offdiagonal_metric_reg, likelihood_wt, metric_wt, ood,
+                                 None if _pre_logjac is None else _pre_logjac[i:i + chunk])
+                for i in range(0, B, chunk)]
+        if len(outs) == 1:
+            return outs[0]
+        merged = {k: torch.cat([o[k] for o in outs]) for k in outs[0] if k != "prior-dict"}
+        if "prior-dict" in outs[0]:
+            merged["prior-dict"] = {k: torch.cat([o["prior-dict"][k] for o in outs]) for k in outs[0]["prior-dict"]}
+        return merged
+
+    def _elbo_chunk(self, x, want_lik, want_jac, add_rec, add_diag, add_off, lw, mw, ood, pre):
+        prog, B, dev = self.program, x.shape[0], x.device
+        x = x.contiguous()
+        z_low, low_elbo, _ = prog.encode(x)
+        logdet = l1 = None
+        if want_jac:
+            if self.training and self.log_jacobian_method == "hutch_with_cg":
+                raise NotImplementedError(
+                    "train-mode Hutchinson+CG surrogate (non_square.py:203-258) needs the reverse-mode sweep "
+                    "(SURVEY.md a14/f1); eval mode uses the exact path like the reference (:133)")
+            x_hat, T = prog.decode(z_low, tangents=True)
+            g = E.gram_cholesky(T, prog.d, self.MAX_ATTEMPTS)
+            self.last_gram = g
+            self._report_attempts(g)
+            logdet = g.logdet
+            l1 = g.l1_diag if add_diag else (g.l1_off if add_off else None)
+        else:
+            x_hat, _ = prog.decode(z_low, tangents=False)      # warm-up: decode only (non_square.py:105-109)
+        rec = E.recon_sqerr(x_hat, x) if add_rec else None
+        if ood:
+            lik = E.elbo_combine(low_elbo, logdet, None, None, None, 1.0, 0.0, 0.0, B, dev)
+            return {"likelihood": lik, "reconstruction-error": rec.view(B, 1)}
+        elbo = E.elbo_combine(low_elbo if want_lik else None, logdet, rec, l1, pre, lw, self.regularization_param, mw,
+                              B, dev)
+        return {"elbo": elbo, "prior-dict": {"elbo": low_elbo.view(B, 1), "low-dim-x": z_low}}
+
+    def _report_attempts(self, g):
+        if self.check_cholesky != "sync":
+            return
+        fail = g.fail.tolist()                                   # one small D2H copy (synchronises the stream)
+        attempts = 1
+        while attempts <= self.MAX_ATTEMPTS and fail[attempts - 1]:
+            attempts += 1
+        if attempts > self.MAX_ATTEMPTS:
+            raise RuntimeError(f"J^T J is not positive definite after {self.MAX_ATTEMPTS} jitter attempts "
+                               "(the reference would retry forever, non_square.py:280-288)")
+        if attempts > 1:
+            print(f"WARNING: Numerical non-invertibility in JtJ observed - {attempts} attempts needed to fix")
+        g.attempts = attempts
+
+    # ------------------------------------------------------------------------------------------
+    def _ood(self, x):
+        return self("elbo", x, ood=True)
+
+    def _extract_latent(self, x, **kwargs):
+        E.require_gpu(x)
+        z_low, _, earliest = self.program.encode(x)
+        return earliest if kwargs["earliest_latent"] else z_low
+
+    def _sample(self, num_samples):
+        return self._fixed_sample(self.program.gaussian.sample(num_samples))
+
+    def _fixed_sample(self, noise):
+        prog = self.program
+        u = prog.gaussian.fixed_sample(noise)
+        E.require_gpu(u, "latent noise")
+        x_hat, _ = prog.decode(prog.prior_inverse(u), tangents=False)
+        return x_hat
+
+    # reference-named helpers, kept for callers that reach into the head -----------------------
+    def flow_forward(self, z_low):
+        return self.program.decode(z_low, tangents=False)[0]
+
+    def jvp_forward(self, z_low, v):
+        """One tangent direction v (B, d): returns (x_hat, J v) like non_square.py:322-329."""
+        x_hat, T = self.program.decode(z_low, tangents=True, eps=v.reshape(*v.shape, 1).contiguous())
+        return x_hat, T.to_dense(1)[:, :, 0].reshape(x_hat.shape)
+
+    def jacobian(self, z_low):
+        """Dense J (B, D, d) -- the tensor the reference stacks at non_square.py:307."""
+        x_hat, T = self.program.decode(z_low, tangents=True)
+        return x_hat, T.to_dense(self.program.d).contiguous()
+
+
+class ManifoldFlowHeadDensity(NonSquareHeadDensity):
+    """Two-step M-flow baseline (non_square.py:341-364): no Jacobian term unless visualising; out of the
+    benchmarked path, kept so ``get_non_square_parameters`` finds it by type name."""
+
+    _jacobian_free = True
+
+    def separate_parameters(self, recurse=True):
+        likelihood = set(self.program.tail.parameters())
+        recon = [p for p in self.parameters() if p not in likelihood]
+        return [(p for p in recon), (p for p in likelihood)]

@@ -1,0 +1,356 @@
+"""Host-side driver of the HIP kernels: tensors in, kernel launches out.
+
+PyTorch provides device memory (caching allocator) and the current HIP stream; every number is
+produced by libcmf_amd.so through the C ABI in include/cmf_amd.h.  There is no CPU path: tensors
+that are not on a GPU raise.
+
+Layouts
+  primal   (B, N) row-major fp32                       -- identical to the reference's tensors
+  tangent  ``Tangent``: T(b, r, col), col = Jacobian column, NC = ceil16(#columns)
+             'panel'  (B, N, NC)   image nets: one J panel per sample
+             'fmajor' (N, B, NC)   MLP nets: feature-major so that a Linear layer is a 1x1
+                                   convolution whose "pixels" are the batch samples
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import F_NONE, F_RELU, F_TANH, F_RAW, O_NONE, O_TANH, O_STANH, ConvPrimalArgs, ConvTangentArgs
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def require_gpu(t, what="input"):
+    if not t.is_cuda:
+        raise RuntimeError(f"cmf_amd: {what} is on {t.device}; the log-density path runs only through the HIP "
+                           "kernels on an AMD GPU (there is no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"cmf_amd: {what} must be float32, got {t.dtype}")
+
+
+def ceil16(n):
+    return (int(n) + 15) // 16 * 16
+
+
+class Tangent:
+    """A stack of Jacobian columns attached to a primal tensor of N elements per sample."""
+
+    def __init__(self, B, N, nc, layout, device, data=None):
+        self.B, self.N, self.nc, self.layout = int(B), int(N), int(nc), layout
+        numel = self.B * self.N * self.nc
+        self.data = data if data is not None else torch.empty(numel, dtype=torch.float32, device=device)
+        assert self.data.numel() >= numel
+
+    @property
+    def t_b(self):
+        return self.N * self.nc if self.layout == "panel" else self.nc
+
+    @property
+    def t_r(self):
+        return self.nc if self.layout == "panel" else self.B * self.nc
+
+    def like(self, N):
+        return Tangent(self.B, N, self.nc, self.layout, self.data.device)
+
+    def to_dense(self, ncols):
+        """(B, N, ncols) torch view/copy for tests and the public jvp API."""
+        if self.layout == "panel":
+            return self.data[: self.B * self.N * self.nc].view(self.B, self.N, self.nc)[:, :, :ncols]
+        return self.data[: self.B * self.N * self.nc].view(self.N, self.B, self.nc).permute(1, 0, 2)[:, :, :ncols]
+
+
+# --------------------------------------------------------------------------------------------------
+# packed weights, cached per parameter version
+# --------------------------------------------------------------------------------------------------
+
+
+class _PackCache:
+    def __init__(self):
+        self._store = {}
+
+    def get(self, weight, taps, transpose=False):
+        key = (id(weight), bool(transpose))
+        ver = (weight._version, weight.data_ptr(), weight.device)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        lib = _lib.load()
+        cout, cin = int(weight.shape[0]), int(weight.shape[1])
+        n = C.c_longlong(0)
+        _lib.check(lib.cmf_pack_weight(None, None, cout, cin, taps, int(transpose), C.byref(n), None), "pack size")
+        out = torch.empty(n.value, dtype=torch.float32, device=weight.device)
+        w = weight.detach().contiguous()
+        _lib.check(lib.cmf_pack_weight(_p(w), _p(out), cout, cin, taps, int(transpose), None, _stream()), "cmf_pack_weight")
+        self._store[key] = (ver, out)
+        return out
+
+
+PACKS = _PackCache()
+
+
+# --------------------------------------------------------------------------------------------------
+# thin wrappers over the C ABI
+# --------------------------------------------------------------------------------------------------
+
+
+def conv_primal(x_ptr_t, x_off, x_b, x_c, x_px, weight, taps, bias, y, y_b, y_c, y_px, B, cin, cout, H, W,
+                imode=F_NONE, mask=None, f_c=0, f_px=0, omode=O_NONE, sw=None, sb=None, g=None, res=None):
+    """One primal conv/linear launch.  ``x_ptr_t`` is the tensor holding the input, ``x_off`` an element offset."""
+    lib = _lib.load()
+    a = ConvPrimalArgs()
+    a.x = C.c_void_p(x_ptr_t.data_ptr() + 4 * int(x_off)); a.x_b, a.x_c, a.x_px = int(x_b), int(x_c), int(x_px)
+    a.f = _p(mask); a.f_c, a.f_px = int(f_c), int(f_px); a.imode = imode
+    a.w = _p(PACKS.get(weight, taps)); a.bias = _p(bias); a.sw = _p(sw); a.sb = _p(sb)
+    a.y = _p(y); a.y_b, a.y_c, a.y_px = int(y_b), int(y_c), int(y_px)
+    a.g = _p(g)
+    a.r = _p(res); a.r_b, a.r_c, a.r_px = int(y_b), int(y_c), int(y_px)
+    a.omode = omode
+    a.B, a.cin, a.cout, a.H, a.W, a.taps = int(B), int(cin), int(cout), int(H), int(W), int(taps)
+    _lib.check(lib.cmf_conv_primal(C.byref(a), _stream()), "cmf_conv_primal")
+
+
+def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_px, np_, cin, cout, H, W, nc,
+                 fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, res_t=None, transpose=False):
+    lib = _lib.load()
+    a = ConvTangentArgs()
+    a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
+    a.f = _p(f); a.f_np, a.f_ci, a.f_px = int(f_np), int(f_ci), int(f_px); a.fmode = fmode
+    a.w = _p(PACKS.get(weight, taps, transpose))
+    a.y = _p(y_t); a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
+    a.r = _p(res_t); a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
+    a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), int(taps)
+    _lib.check(lib.cmf_conv_tangent(C.byref(a), _stream()), "cmf_conv_tangent")
+
+
+def gather_primal(src, idx, n_out, out=None):
+    """out(b, r) = idx[r] >= 0 ? src(b, idx[r]) : 0.  src: (B, N...) contiguous."""
+    B = src.shape[0]
+    src2 = src.reshape(B, -1)
+    if out is None:
+        out = torch.empty(B, n_out, dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().cmf_gather_primal(_p(src2), src2.shape[1], _p(out), n_out, _p(idx), n_out, B, _stream()),
+               "cmf_gather_primal")
+    return out
+
+
+def gather_tangent(T, idx, n_out):
+    out = T.like(n_out)
+    _lib.check(_lib.load().cmf_gather_tangent(_p(T.data), T.t_b, T.t_r, _p(out.data), out.t_b, out.t_r, _p(idx), n_out,
+                                              T.nc, T.B, _stream()), "cmf_gather_tangent")
+    return out
+
+
+def seed_tangent(B, N, nc, layout, col_of, d, device, eps=None):
+    T = Tangent(B, N, nc, layout, device)
+    S = 0 if eps is None else int(eps.shape[2])
+    _lib.check(_lib.load().cmf_seed_tangent(_p(T.data), T.t_b, T.t_r, _p(col_of), N, nc, _p(eps), d, S, B, _stream()),
+               "cmf_seed_tangent")
+    return T
+
+
+def acl_primal(z, y, maps, decode, lj=None):
+    B = z.shape[0]
+    z2, y2 = z.view(B, -1), y.view(B, -1)
+    _lib.check(_lib.load().cmf_acl_primal(_p(z2), z2.shape[1], _p(y2), y2.shape[1], _p(maps["zi"]), _p(maps["si"]),
+                                          _p(maps["ti"]), maps["n"], B, int(decode), _p(lj), _stream()), "cmf_acl_primal")
+
+
+def acl_tangent(T, YT, z, y, g, maps):
+    B = z.shape[0]
+    z2, y2 = z.view(B, -1), y.view(B, -1)
+    _lib.check(_lib.load().cmf_acl_tangent(_p(T.data), T.t_b, T.t_r, _p(YT.data), YT.t_b, YT.t_r, T.nc, _p(z2),
+                                           z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]), _p(maps["si"]),
+                                           _p(maps["ti"]), maps["n"], B, _stream()), "cmf_acl_tangent")
+
+
+class GramResult:
+    __slots__ = ("jtj", "logdet", "l1_off", "l1_diag", "info", "fail")
+
+
+def gram_cholesky(T, d, max_attempts=6, eps0=1e-6):
+    """Fused Gram + Cholesky with the reference's whole-batch jitter retries enqueued back to back."""
+    lib = _lib.load()
+    dev = T.data.device
+    r = GramResult()
+    r.jtj = torch.empty(T.B, d, d, dtype=torch.float32, device=dev)
+    r.logdet = torch.empty(T.B, dtype=torch.float32, device=dev)
+    r.l1_off = torch.empty(T.B, dtype=torch.float32, device=dev)
+    r.l1_diag = torch.empty(T.B, dtype=torch.float32, device=dev)
+    r.info = torch.empty(T.B, dtype=torch.int32, device=dev)
+    r.fail = torch.empty(8, dtype=torch.int32, device=dev)
+    _lib.check(lib.cmf_gram_cholesky(_p(T.data), T.t_b, T.t_r, T.N, T.nc, d, T.B, _p(r.jtj), _p(r.logdet), _p(r.l1_off),
+                                     _p(r.l1_diag), _p(r.info), _p(r.fail), _stream()), "cmf_gram_cholesky")
+    for a in range(1, max_attempts):
+        _lib.check(lib.cmf_cholesky_retry(_p(r.jtj), d, T.B, a, eps0, _p(r.logdet), _p(r.l1_diag), _p(r.info), _p(r.fail),
+                                          _stream()), "cmf_cholesky_retry")
+    return r
+
+
+def prehead(x, noise, a, c, logit):
+    B = x.shape[0]
+    n = x[0].numel()
+    y = torch.empty_like(x)
+    lj = torch.empty(B, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().cmf_prehead(_p(x), _p(noise), _p(y), _p(lj), float(a), float(c), int(logit), n, B, _stream()),
+               "cmf_prehead")
+    return y, lj
+
+
+def prehead_inverse(y, a, c, logit):
+    x = torch.empty_like(y)
+    _lib.check(_lib.load().cmf_prehead_inverse(_p(y), _p(x), float(a), float(c), int(logit), y.numel(), _stream()),
+               "cmf_prehead_inverse")
+    return x
+
+
+def gaussian_logprob(z, lp):
+    B = z.shape[0]
+    z2 = z.view(B, -1)
+    _lib.check(_lib.load().cmf_gaussian_logprob(_p(z2), z2.shape[1], z2.shape[1], B, _p(lp), _stream()),
+               "cmf_gaussian_logprob")
+
+
+def affine_prior(z, log_scale, shift, decode, lj=None):
+    B = z.shape[0]
+    z2 = z.view(B, -1)
+    _lib.check(_lib.load().cmf_affine_prior(_p(z2), z2.shape[1], _p(log_scale.detach().contiguous()),
+                                            _p(shift.detach().contiguous()), z2.shape[1], B, int(decode), _p(lj), _stream()),
+               "cmf_affine_prior")
+
+
+def recon_sqerr(xh, x):
+    B = x.shape[0]
+    rec = torch.empty(B, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().cmf_recon_sqerr(_p(xh.reshape(B, -1)), _p(x.reshape(B, -1)), x[0].numel(), B, _p(rec), _stream()),
+               "cmf_recon_sqerr")
+    return rec
+
+
+def elbo_combine(low, logdet, rec, l1, pre, wl, lam, wm, B, device):
+    out = torch.empty(B, 1, dtype=torch.float32, device=device)
+    _lib.check(_lib.load().cmf_elbo_combine(_p(low), _p(logdet), _p(rec), _p(l1), _p(pre), float(wl), float(lam), float(wm),
+                                            B, _p(out), _stream()), "cmf_elbo_combine")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# coupler networks
+# --------------------------------------------------------------------------------------------------
+
+
+class NetView:
+    """Where a coupler network reads its input inside the current primal / tangent tensors."""
+
+    def __init__(self, geom, cin, chan_off=0, chan_step=1, mask=None):
+        self.geom, self.cin, self.chan_off, self.chan_step, self.mask = geom, cin, chan_off, chan_step, mask
+
+
+class Geometry:
+    """Shape of the tensor an ACL acts on: image (C, H, W) or flat (F,)."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(s) for s in shape)
+        self.image = len(self.shape) == 3
+        if self.image:
+            self.C, self.H, self.W = self.shape
+            self.HW = self.H * self.W
+        else:
+            assert len(self.shape) == 1
+            self.C, self.H, self.W, self.HW = self.shape[0], 1, 1, 1
+        self.N = int(np.prod(self.shape))
+
+
+def _resnet_parts(net):
+    body = net.module
+    blocks = [m for m in body if hasattr(m, "conv1")]
+    convs = [m for m in body if isinstance(m, nn.Conv2d)]
+    return convs[0], blocks, convs[-1]
+
+
+def net_primal(net, z, view):
+    """Primal forward of a coupler network on the current tensor ``z`` (B, *geom.shape).
+    Returns (y (B, cout, ...), g or None, acts: activation tensors the tangent pass differentiates through)."""
+    geo, B, dev = view.geom, z.shape[0], z.device
+    if net.kind == "resnet":
+        conv0, blocks, convf = _resnet_parts(net)
+        hid, cout, H, W, HW = conv0.out_channels, convf.out_channels, geo.H, geo.W, geo.HW
+        new = lambda c: torch.empty(B, c, H, W, dtype=torch.float32, device=dev)
+        a = new(hid)
+        conv_primal(z, view.chan_off * HW, geo.C * HW, view.chan_step * HW, 1, conv0.weight, 9, None, a, hid * HW, HW, 1,
+                    B, view.cin, hid, H, W, imode=F_RAW if view.mask is not None else F_NONE, mask=view.mask, f_c=HW, f_px=1)
+        acts = [a]
+        for blk in blocks:
+            c1 = new(hid)
+            conv_primal(a, 0, hid * HW, HW, 1, blk.conv1.weight, 9, blk.conv1.bias, c1, hid * HW, HW, 1, B, hid, hid, H, W,
+                        imode=F_RELU)
+            a2 = new(hid)
+            conv_primal(c1, 0, hid * HW, HW, 1, blk.conv2.weight, 9, blk.conv2.bias, a2, hid * HW, HW, 1, B, hid, hid, H, W,
+                        imode=F_RELU, res=a)
+            acts += [c1, a2]
+            a = a2
+        y, g = new(cout), new(cout)
+        conv_primal(a, 0, hid * HW, HW, 1, convf.weight, 1, convf.bias, y, cout * HW, HW, 1, B, hid, cout, H, W,
+                    imode=F_RELU, omode=O_STANH, sw=net.weights.detach().reshape(-1), sb=net.bias.detach().reshape(-1), g=g)
+        return y, g, acts
+    # MLP: pixels = batch samples, channels = features
+    lins = [m for m in net if isinstance(m, nn.Linear)]
+    F_in = geo.C
+    h, h_c, h_px, h_off, cin = z, view.chan_step, F_in, view.chan_off, view.cin
+    acts = []
+    for i, lin in enumerate(lins):
+        last = i == len(lins) - 1
+        out = torch.empty(B, lin.out_features, dtype=torch.float32, device=dev)
+        conv_primal(h, h_off, 0, h_c, h_px, lin.weight, 1, lin.bias, out, 0, 1, lin.out_features, 1, cin, lin.out_features,
+                    1, B, omode=O_NONE if last else O_TANH)
+        if not last:
+            acts.append(out)
+        h, h_c, h_px, h_off, cin = out, 1, lin.out_features, 0, lin.out_features
+    return h, None, acts
+
+
+def net_tangent(net, T, view, acts, transpose_packs=False):
+    """Push all Jacobian columns of ``T`` through the coupler network; returns the raw tangent of the
+    network's pre-activation output (the ScaledTanh derivative ``g`` is applied by acl_tangent)."""
+    geo, B, nc, dev = view.geom, T.B, T.nc, T.data.device
+    if net.kind == "resnet":
+        conv0, blocks, convf = _resnet_parts(net)
+        hid, cout, H, W, HW = conv0.out_channels, convf.out_channels, geo.H, geo.W, geo.HW
+        new = lambda c: Tangent(B, c * HW, nc, "panel", dev)
+        pn = lambda c: (c * HW * nc, HW * nc, nc)          # (np, chan, px) strides of a panel with c channels
+        h = new(hid)
+        conv_tangent(T.data, view.chan_off * HW * nc, T.t_b, view.chan_step * HW * nc, nc, conv0.weight, 9, h.data, *pn(hid),
+                     B, view.cin, hid, H, W, nc, fmode=F_RAW if view.mask is not None else F_NONE, f=view.mask, f_np=0,
+                     f_ci=HW, f_px=1)
+        u, h2 = new(hid), new(hid)
+        for k, blk in enumerate(blocks):
+            a_in, c1 = acts[2 * k], acts[2 * k + 1]
+            conv_tangent(h.data, 0, *pn(hid), blk.conv1.weight, 9, u.data, *pn(hid), B, hid, hid, H, W, nc, fmode=F_RELU,
+                         f=a_in, f_np=hid * HW, f_ci=HW, f_px=1)
+            conv_tangent(u.data, 0, *pn(hid), blk.conv2.weight, 9, h2.data, *pn(hid), B, hid, hid, H, W, nc, fmode=F_RELU,
+                         f=c1, f_np=hid * HW, f_ci=HW, f_px=1, res_t=h.data)
+            h, h2 = h2, h
+        yt = new(cout)
+        conv_tangent(h.data, 0, *pn(hid), convf.weight, 1, yt.data, *pn(cout), B, hid, cout, H, W, nc, fmode=F_RELU,
+                     f=acts[-1], f_np=hid * HW, f_ci=HW, f_px=1)
+        return yt
+    lins = [m for m in net if isinstance(m, nn.Linear)]
+    x_t, x_off, x_ci, cin = T.data, view.chan_off * B * nc, view.chan_step * B * nc, view.cin
+    fmode, f, f_px = F_NONE, None, 0
+    out = None
+    for i, lin in enumerate(lins):
+        out = Tangent(B, lin.out_features, nc, "fmajor", dev)
+        conv_tangent(x_t, x_off, 0, x_ci, nc, lin.weight, 1, out.data, 0, B * nc, nc, 1, cin, lin.out_features, 1, B, nc,
+                     fmode=fmode, f=f, f_np=0, f_ci=1, f_px=f_px)
+        if i < len(acts):
+            fmode, f, f_px = F_TANH, acts[i], lin.out_features
+        x_t, x_off, x_ci, cin = out.data, 0, B * nc, lin.out_features
+    return out

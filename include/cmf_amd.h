@@ -1,0 +1,170 @@
+/* cmf_amd.h -- C ABI of libcmf_amd.so: the MI355X (gfx950) kernels of the non-square-flow
+ * log-density path of k-flouris/cmf.
+ *
+ * The reference is pure Python/PyTorch and has no FFI; each entry point below replaces a group of
+ * ATen dispatches issued by the reference functions cited next to it (paths relative to the
+ * reference repository root).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (or int32 where stated); the caller owns all
+ *     buffers (no hidden allocations), sizes/strides are in ELEMENTS, not bytes;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous;
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
+ *     CMF_E* code for invalid arguments.  Nothing throws across this boundary;
+ *   - no global mutable state: every call is re-entrant (one Python thread per device is fine).
+ *
+ * Data layouts
+ *   primal tensor   P(b, r)        = p[b*p_b + r*p_r]                  (B, N) row-major, = torch layout
+ *   tangent tensor  T(b, r, col)   = t[b*t_b + r*t_r + col]            col = Jacobian column, NC = ceil16(d)
+ *       image nets : t_b = N*NC, t_r = NC          ("J panel" per sample: (B, C, H, W, NC))
+ *       MLP nets   : t_b = NC,   t_r = B*NC        (feature-major: (F, B, NC))
+ */
+#ifndef CMF_AMD_H
+#define CMF_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMF_EINVAL (-1)   /* bad shape / stride / mode                                   */
+#define CMF_ERANGE (-2)   /* size exceeds what the kernel's index arithmetic supports    */
+
+/* factor modes: how the per-(channel,pixel) multiplier applied to a conv/linear INPUT is derived
+ * from the primal tensor `f` (jvp_layers.py:38-47 activation rules, applied on load) */
+#define CMF_F_NONE 0      /* no multiplier                                               */
+#define CMF_F_RELU 1      /* (f > 0)           relu'  : jvp_layers.py:40                 */
+#define CMF_F_TANH 2      /* 1 - f*f           tanh'  with f = tanh output: :42-44       */
+#define CMF_F_RAW  3      /* f itself          checkerboard mask: acl.py:54              */
+
+/* primal epilogues */
+#define CMF_O_NONE  0
+#define CMF_O_TANH  1     /* y = tanh(v)                         (MLP hidden layer)                  */
+#define CMF_O_STANH 2     /* y = w*tanh(v)+b2, g = w*(1-tanh^2)  (ScaledTanh2dModule networks.py:96-113) */
+
+const char* cmf_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight packing.  w: [cout][cin][kh][kw] (nn.Conv2d / nn.Linear with kh=kw=1).
+ * out: [ncog][taps][cin_pad][64] with cin_pad = ceil8(cin), ncog = ceil(cout/64); zero padded.
+ * transpose != 0 packs the adjoint operator (cout<->cin swapped, taps flipped) used by the
+ * reverse-mode sweep of the Hutchinson path (non_square.py:190-201).
+ * Returns the number of floats written through *out_floats when out == NULL (size query).       */
+int cmf_pack_weight(const float* w, float* out, int cout, int cin, int taps, int transpose,
+                    long long* out_floats, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tangent convolution / linear layer on fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * Replaces, for all d Jacobian columns at once, the tangent half of get_conv2d_jvp / get_linear_jvp
+ * (jvp_layers.py:49-64) fused with the activation rule of the preceding layer (:38-47) and the
+ * residual add of ResidualBlock.jvp (networks.py:62-79):
+ *     y(np, co, px, :) = sum_{ci,tap} W[co][ci][tap] * F(np, ci, px+tap) * x(np, ci, px+tap, :)  [+ r(np, co, px, :)]
+ * taps == 9: 3x3, stride 1, zero padding 1 over an H x W image; taps == 1: 1x1 over H*W flat pixels
+ * (an MLP layer is the 1x1 case with pixels = batch samples).                                    */
+typedef struct {
+  const float* x; long long x_np, x_ci, x_px;   /* input tangent tensor, NC contiguous columns       */
+  const float* f; long long f_np, f_ci, f_px;   /* primal tensor the factor is derived from (or NULL) */
+  int fmode;                                    /* CMF_F_*                                            */
+  const float* w;                               /* packed by cmf_pack_weight                          */
+  float* y;       long long y_np, y_co, y_px;
+  const float* r; long long r_np, r_co, r_px;   /* residual (same shape as y) or NULL                 */
+  int np, cin, cout, H, W, nc, taps;
+} cmf_conv_tangent_args;
+int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Primal convolution / linear layer on fp32 MFMA: nn.Conv2d / nn.Linear forward of the coupler
+ * networks (networks.py:50-60, :103-106, :206-224) with the preceding activation fused on load and
+ * bias / residual / tanh epilogues:
+ *     v(b, co, px) = sum W[co][ci][tap] * in(b, ci, px+tap) + bias[co] [+ r(b, co, px)]
+ *     in = x | relu(x) | x*f        (imode CMF_F_NONE | CMF_F_RELU | CMF_F_RAW with mask f(ci,px))
+ * omode CMF_O_NONE: y = v;  CMF_O_TANH: y = tanh(v);  CMF_O_STANH: y = sw[co]*tanh(v)+sb[co] and
+ * g = sw[co]*(1-tanh(v)^2) (the tangent multiplier of ScaledTanh2dModule.jvp, networks.py:108-113).
+ * Element (b, c, px) of a tensor t lives at t[b*t_b + c*t_c + px*t_px].                           */
+typedef struct {
+  const float* x; long long x_b, x_c, x_px;
+  const float* f; long long f_c, f_px;          /* CMF_F_RAW mask (shared over the batch) or NULL     */
+  int imode;
+  const float* w; const float* bias;            /* packed weights; bias[cout] or NULL                 */
+  const float* sw; const float* sb;             /* CMF_O_STANH per-channel scale / offset             */
+  float* y;       long long y_b, y_c, y_px;
+  float* g;                                     /* CMF_O_STANH derivative factor (strides of y)|NULL  */
+  const float* r; long long r_b, r_c, r_px;
+  int omode;
+  int B, cin, cout, H, W, taps;
+} cmf_conv_primal_args;
+int cmf_conv_primal(const cmf_conv_primal_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Affine coupling transforms (acl.py:43-66, :101-146), in place on the primal / tangent tensors.
+ * The three mask types (checkerboard acl.py:68-78, split-channel :185-189, alternating :207-214)
+ * are all expressed by index maps over the n_mod modified elements of a sample:
+ *   zi[e]: element of z that is modified; ti[e] / si[e]: elements of the coupler output holding its
+ *   shift / log-scale (couplers.py:52-59 chunking).  Pass-through elements are untouched.
+ * encode (x_to_z): z = (x + t) * exp(s);  if lj != NULL: lj[b] += sum_e s       (log-jac, acl.py:22-23)
+ * decode (z_to_x): x = z * exp(-s) - t                                                             */
+int cmf_acl_primal(float* z, long long z_b, const float* y, long long y_b, const int* zi, const int* si,
+                   const int* ti, int n_mod, int B, int decode, float* lj, void* stream);
+/* tangent: T(b, zi[e], :) = exp(-s) * (T(b, zi[e], :) - z_old * sdot) - tdot   (acl.py:61-64, :137-144)
+ *   sdot = gs * yt(b, si[e], :), tdot = gt * yt(b, ti[e], :), gs/gt = g(b, si[e]) / g(b, ti[e]) or 1 when
+ *   g == NULL; z_old = z(b, zi[e]) BEFORE cmf_acl_primal decode is applied; s from y.              */
+int cmf_acl_tangent(float* t, long long t_b, long long t_r, const float* yt, long long yt_b, long long yt_r,
+                    int nc, const float* z, long long z_b, const float* y, long long y_b, const float* g,
+                    const int* zi, const int* si, const int* ti, int n_mod, int B, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Index-map moves: squeeze / unsqueeze (reshaping.py:89-114), split padding (split.py:50-52), tail
+ * gather / scatter (non_square.py:381-384, :397-404), layout changes.
+ * out(b, r) = idx[r] >= 0 ? in(b, idx[r]) : 0,   r < n_out.                                        */
+int cmf_gather_primal(const float* in, long long in_b, float* out, long long out_b, const int* idx,
+                      int n_out, int B, void* stream);
+int cmf_gather_tangent(const float* in, long long in_b, long long in_r, float* out, long long out_b,
+                       long long out_r, const int* idx, int n_out, int nc, int B, void* stream);
+/* Seed tangents at the tail (non_square.py:303-304, :406-410): col_of[r] = Jacobian column whose unit
+ * vector lands on element r (or -1).  eps == NULL: T(b, r, c) = (col_of[r] == c)  (identity seed, exact
+ * path); else T(b, r, c) = eps[b][col_of[r]][c] for c < S (Hutchinson probes, non_square.py:204-215).  */
+int cmf_seed_tangent(float* t, long long t_b, long long t_r, const int* col_of, int n_rows, int nc,
+                     const float* eps, int d, int S, int B, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused J^T J Gram (MFMA) + Cholesky + log-det + metric L1 terms: replaces
+ * non_square.py:307-308 (stack + bmm), :280-294 (cholesky, 2*sum log diag) and :87-100 (g_kk / g_ij).
+ *   jtj   [B][d][d]  out, the (possibly jittered) Gram matrix;  logdet, l1_off, l1_diag: [B]
+ *   info  [B] int32: 0 ok, k+1 = non-positive / non-finite pivot at column k
+ *   fail  int32[8]: fail[a] != 0 iff attempt a failed for ANY sample (whole-batch retry, :284-288)
+ * cmf_gram_cholesky is attempt 0.  cmf_cholesky_retry(attempt = a >= 1) returns immediately on the
+ * device unless fail[a-1] != 0; otherwise it adds eps * 10^(a-1) to the diagonal of EVERY sample's
+ * jtj (in place) and refactorises.  The host may enqueue all retries without synchronising.       */
+int cmf_gram_cholesky(const float* t, long long t_b, long long t_r, int n_rows, int nc, int d, int B,
+                      float* jtj, float* logdet, float* l1_off, float* l1_diag, int* info, int* fail,
+                      void* stream);
+int cmf_cholesky_retry(float* jtj, int d, int B, int attempt, float eps0, float* logdet, float* l1_diag,
+                       int* info, int* fail, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small per-sample reductions / elementwise maps.                                                 */
+/* pre-head chain (wrapper.py:28-30, math.py:41-105): y = a*(x + u) + c; if logit: y = log(y)-log(1-y) and
+ * lj[b] = n*log|a| + sum(-log(yc) - log(1-yc)), yc = clamp(a*(x+u)+c, 1e-7, 1-1e-7).  u may be NULL.     */
+int cmf_prehead(const float* x, const float* u, float* y, float* lj, float a, float c, int logit, int n,
+                int B, void* stream);
+/* inverse of the pre-head chain for sampling (math.py:45-46, :83-84, :100-101): x = (sigmoid(y) - c) / a */
+int cmf_prehead_inverse(const float* y, float* x, float a, float c, int logit, long long n_total, void* stream);
+/* lp[b] += -n/2 log(2 pi) - 1/2 sum z^2      (gaussian.py:9-22 with mean 0, stddev 1)              */
+int cmf_gaussian_logprob(const float* z, long long z_b, int n, int B, float* lp, void* stream);
+/* 2-D prior AffineBijection (affine.py:24-34): encode u = z*exp(ls)+sh, lj[b] += sum ls; decode inverse */
+int cmf_affine_prior(float* z, long long z_b, const float* log_scale, const float* shift, int n, int B,
+                     int decode, float* lj, void* stream);
+/* rec[b] = sum_r (xh(b,r) - x(b,r))^2        (non_square.py:111-114)                               */
+int cmf_recon_sqerr(const float* xh, const float* x, int n, int B, float* rec, void* stream);
+/* elbo[b] = wl*(low[b] - logdet[b]/2) - lam*rec[b] - wm*l1[b] + pre[b]; NULL inputs count as 0
+ * (non_square.py:85, :126-129 and exact.py:27 for the pre-head log-jacobians)                      */
+int cmf_elbo_combine(const float* low, const float* logdet, const float* rec, const float* l1, const float* pre,
+                     float wl, float lam, float wm, int B, float* elbo, void* stream);
+/* Hutchinson pieces (non_square.py:190-201, :232-256).  w(b, :, s) = J(b)^T u(b) for S probe columns:
+ * w[b][k][s] = sum_r T(b, r, k) * U(b, r, s) with T the full d-column Jacobian panel (exact J^T J eps);
+ * the matrix-free form runs cmf_conv_tangent with transposed packs instead.        */
+int cmf_hutch_value(const float* u, const float* w, int d, int S, int B, float* val, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMF_AMD_H */

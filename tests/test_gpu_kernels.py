@@ -1,0 +1,82 @@
+"""Unit parity of the individual HIP kernels against plain PyTorch fp32 on random data (``-m gpu``)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("cin,cout,H,W,taps,nc", [
+    (64, 64, 14, 14, 9, 64), (64, 64, 28, 28, 9, 32), (2, 64, 14, 14, 9, 16), (64, 4, 14, 14, 1, 64),
+    (64, 64, 16, 16, 9, 16), (3, 24, 9, 11, 9, 16), (17, 40, 5, 7, 9, 32), (64, 2, 28, 28, 1, 16), (130, 70, 1, 37, 1, 16),
+])
+@pytest.mark.parametrize("fmode", ["none", "relu", "tanh", "raw"])
+def test_conv_tangent(cin, cout, H, W, taps, nc, fmode):
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(cin * 1000 + cout + H)
+    B = 3
+    w = torch.randn(cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1, generator=gen) / (cin * taps) ** 0.5
+    x = torch.randn(B, cin, H, W, nc, generator=gen)
+    prim = torch.randn(B, cin, H, W, generator=gen)
+    res = torch.randn(B, cout, H, W, nc, generator=gen)
+    fac = {"none": torch.ones_like(prim), "relu": (prim > 0).float(), "tanh": 1 - torch.tanh(prim) ** 2,
+           "raw": (prim > 0.3).float()}[fmode]
+    src = {"none": None, "relu": prim, "tanh": torch.tanh(prim), "raw": (prim > 0.3).float()}[fmode]
+    xin = (x * fac.unsqueeze(-1)).permute(0, 4, 1, 2, 3).reshape(B * nc, cin, H, W)
+    want = F.conv2d(xin, w, padding=1 if taps == 9 else 0).reshape(B, nc, cout, H, W).permute(0, 2, 3, 4, 1) + res
+    HW = H * W
+    wd = torch.nn.Parameter(w.cuda())
+    y = torch.full((B, cout, H, W, nc), float("nan"), device="cuda")
+    E.conv_tangent(x.cuda(), 0, cin * HW * nc, HW * nc, nc, wd, taps, y, cout * HW * nc, HW * nc, nc, B, cin, cout, H, W, nc,
+                   fmode={"none": E.F_NONE, "relu": E.F_RELU, "tanh": E.F_TANH, "raw": E.F_RAW}[fmode],
+                   f=None if src is None else src.cuda(), f_np=cin * HW, f_ci=HW, f_px=1, res_t=res.cuda())
+    assert rel(y, want) < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,H,W,taps", [(64, 64, 28, 28, 9), (1, 64, 28, 28, 9), (64, 2, 28, 28, 1), (2, 64, 14, 14, 9),
+                                               (3, 64, 32, 32, 9), (64, 24, 16, 16, 1), (5, 33, 7, 19, 9), (70, 130, 1, 300, 1)])
+@pytest.mark.parametrize("imode", ["none", "relu", "raw"])
+def test_conv_primal(cin, cout, H, W, taps, imode):
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(cin + cout * 7 + H)
+    B = 2
+    k = 3 if taps == 9 else 1
+    w = torch.randn(cout, cin, k, k, generator=gen) / (cin * taps) ** 0.5
+    b = torch.randn(cout, generator=gen)
+    x = torch.randn(B, cin, H, W, generator=gen)
+    mask = (torch.randn(cin, H, W, generator=gen) > 0).float()
+    res = torch.randn(B, cout, H, W, generator=gen)
+    sw, sb = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen)
+    xin = {"none": x, "relu": torch.relu(x), "raw": x * mask}[imode]
+    v = F.conv2d(xin, w, b, padding=1 if taps == 9 else 0) + res
+    HW = H * W
+    wd, y, gout = torch.nn.Parameter(w.cuda()), torch.empty(B, cout, H, W, device="cuda"), torch.empty(B, cout, H, W, device="cuda")
+    E.conv_primal(x.cuda(), 0, cin * HW, HW, 1, wd, taps, b.cuda(), y, cout * HW, HW, 1, B, cin, cout, H, W,
+                  imode={"none": E.F_NONE, "relu": E.F_RELU, "raw": E.F_RAW}[imode], mask=mask.cuda(), f_c=HW, f_px=1,
+                  omode=E.O_STANH, sw=sw.cuda(), sb=sb.cuda(), g=gout, res=res.cuda())
+    t = torch.tanh(v)
+    assert rel(y, sw.view(1, -1, 1, 1) * t + sb.view(1, -1, 1, 1)) < 2e-5
+    assert rel(gout, sw.view(1, -1, 1, 1) * (1 - t * t)) < 2e-5
+
+
+@pytest.mark.parametrize("N,d,layout", [(784, 64, "panel"), (3072, 128, "panel"), (21, 10, "fmajor"), (3, 3, "fmajor"), (50, 33, "panel")])
+def test_gram_cholesky(N, d, layout):
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(N + d)
+    B, nc = 5, E.ceil16(d)
+    J = torch.zeros(B, N, nc)
+    J[:, :, :d] = torch.randn(B, N, d, generator=gen) + (0.5 if N < d + 2 else 0) * torch.eye(N, d)
+    data = J if layout == "panel" else J.permute(1, 0, 2)
+    T = E.Tangent(B, N, nc, layout, "cuda", data=data.contiguous().reshape(-1).cuda())
+    gr = E.gram_cholesky(T, d)
+    G = torch.einsum("bni,bnj->bij", J[:, :, :d].double(), J[:, :, :d].double())
+    assert rel(gr.jtj, G) < 1e-5
+    assert rel(gr.logdet, torch.linalg.slogdet(G)[1]) < 1e-4
+    diag = torch.diagonal(G, dim1=1, dim2=2).abs().sum(1)
+    assert rel(gr.l1_diag, diag) < 1e-5 and rel(gr.l1_off, G.abs().sum((1, 2)) - diag) < 1e-5
+    assert gr.fail.tolist()[0] == 0

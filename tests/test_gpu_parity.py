@@ -1,0 +1,193 @@
+"""Parity of the HIP path (through the C ABI) against the reference-generated golden vectors and the
+CPU oracle.  Needs an MI355X: run with ``-m gpu``.
+
+Tolerances: log-prob / likelihood term 1e-4 relative, g_ij loss 1e-4 relative,
+reconstruction 1e-5 relative (fp32; the oracle itself agrees with an fp64 evaluation to ~1e-6).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_model
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["c1_sphere", "c1_sphere_d2", "c2a_power", "c2b_hepmass", "mini_mnist", "mini_cifar", "mini_mnist_small"]
+ALL = SMALL + ["c3_mnist_full"]
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def build(name):
+    import cmf_amd
+    from cmf_amd.recipe import fill_state_dict
+    g, meta = load_golden(name)
+    cfg = cmf_amd.get_config(meta["dataset"], **meta["overrides"])
+    dens = cmf_amd.get_density(cmf_amd.get_schema(cfg), g["x"])
+    dens.load_state_dict(fill_state_dict(dens.state_dict(), seed=meta["recipe_seed"]), strict=True)
+    dens = dens.cuda().eval()
+    return g, meta, cfg, dens
+
+
+def inner(dens, dequant):
+    """Skip the DequantizationDensity wrapper so the test controls the noise (x + u fed directly)."""
+    return dens.module.density if dequant else dens
+
+
+def find_head(dens):
+    m = dens
+    while type(m).__name__ != "NonSquareHeadDensity":
+        mods = m._modules
+        m = mods.get("module") or mods.get("density") or mods.get("prior")
+    return m
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_elbo_matches_reference_vectors(name):
+    g, meta, cfg, dens = build(name)
+    dequant = "noise" in g
+    x = (g["x"] + g["noise"]) if dequant else g["x"]
+    with torch.no_grad():
+        for i, (lw, mw, rec, off, diag) in enumerate(meta["elbo_combos"]):
+            out = inner(dens, dequant).elbo(x.cuda(), likelihood_wt=lw, metric_wt=mw, add_reconstruction=rec,
+                                            add_offdiagonal_metric_reg=off, add_diagonal_metric_reg=diag)
+            assert out["elbo"].shape == (x.shape[0], 1)
+            assert rel(out["elbo"], g[f"elbo_{i}"]) < 1e-4, (name, i)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_parts_match_reference_vectors(name):
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    y = g["head_input"].cuda()
+    with torch.no_grad():
+        z_low, low_elbo, earliest = head.program.encode(y)
+        assert rel(z_low, g["z_low"]) < 1e-5
+        assert rel(low_elbo.view(-1, 1), g["low_dim_elbo"]) < 1e-5
+        assert rel(earliest, g["earliest_latent"]) < 1e-5
+        x_hat, J = head.jacobian(z_low)
+        assert rel(x_hat, g["x_hat"]) < 1e-5
+        if "J" in g:
+            assert rel(J, g["J"]) < 1e-4
+        head.elbo(y, add_offdiagonal_metric_reg=True)
+        gr = head.last_gram
+        assert rel(gr.jtj, g["jtj"]) < 1e-4
+        assert rel(gr.logdet.view(-1, 1), g["logdet"]) < 1e-4           # log-det itself, 1e-4 relative
+        assert gr.attempts == 1 and int(gr.info.abs().max()) == 0
+        d = g["jtj"].shape[1]
+        off = g["jtj"].abs().sum((1, 2)) - torch.diagonal(g["jtj"], dim1=1, dim2=2).abs().sum(1)
+        assert rel(gr.l1_off, off) < 1e-4                                 # g_ij loss
+        assert rel(gr.l1_diag, torch.diagonal(g["jtj"], dim1=1, dim2=2).abs().sum(1)) < 1e-4
+        # likelihood term = low_dim_elbo - logdet/2 (the "log-prob" of the north star)
+        lik = low_elbo.cpu().view(-1, 1) - gr.logdet.cpu().view(-1, 1) / 2
+        assert rel(lik, g["low_dim_elbo"] - g["logdet"] / 2) < 1e-4
+    if "prehead_logjac" in g and g["prehead_logjac"].abs().max() > 0:
+        xin = (g["x"] + g["noise"]).cuda()
+        m, lj = dens.module.density, torch.zeros(xin.shape[0], 1, device="cuda")
+        while m is not head:
+            r = m.bijection.x_to_z(xin)
+            xin, lj = r["z"], lj + r["log-jac"]
+            m = m.prior
+        assert rel(xin, g["head_input"]) < 1e-5 and rel(lj, g["prehead_logjac"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_ood_latent_sample_api(name):
+    g, meta, cfg, dens = build(name)
+    dequant = "noise" in g
+    x = ((g["x"] + g["noise"]) if dequant else g["x"]).cuda()
+    d = inner(dens, dequant)
+    with torch.no_grad():
+        o = d.ood(x.clone())
+        assert set(o) == {"likelihood", "reconstruction-error"}
+        assert rel(o["likelihood"], g["ood_likelihood"]) < 1e-4
+        assert rel(o["reconstruction-error"], g["ood_recon"]) < 1e-4
+        assert rel(d.extract_latent(x.clone(), earliest_latent=False), g["extract_latent"]) < 1e-5
+        assert rel(d.extract_latent(x.clone(), earliest_latent=True), g["extract_earliest"]) < 1e-5
+        assert rel(dens.fixed_sample(g["sample_noise"].cuda()), g["fixed_sample"]) < 1e-4
+        assert rel(dens.fixed_sample()[:4], g["fixed_sample_default"]) < 1e-4
+        s = dens.sample(5)
+        assert s.shape == (5, *g["x"].shape[1:]) and torch.isfinite(s).all()
+
+
+@pytest.mark.parametrize("name", ["c1_sphere", "c2b_hepmass", "mini_mnist", "mini_cifar"])
+def test_matches_oracle_on_fresh_inputs(name):
+    """Different seed than the fixture: HIP path vs the CPU oracle on the same inputs."""
+    from oracle import cmf_oracle as O
+    g, meta, cfg, dens = build(name)
+    _, schema, x_shape, ops, sd = golden_model(meta)
+    gen = torch.Generator().manual_seed(99)
+    B = 5
+    if len(x_shape) == 3:
+        x = torch.randint(0, 256, (B, *x_shape), generator=gen).float() + torch.rand(B, *x_shape, generator=gen)
+    else:
+        x = torch.randn(B, *x_shape, generator=gen)
+    dequant = "noise" in g
+    with torch.no_grad():
+        want = O.elbo(sd, ops, x, add_offdiagonal_metric_reg=True, noise=torch.zeros_like(x), return_parts=True)
+        got = inner(dens, dequant).elbo(x.cuda(), add_offdiagonal_metric_reg=True)
+    assert rel(got["elbo"], want["elbo"]) < 1e-4
+    head = find_head(dens)
+    assert rel(head.last_gram.logdet.view(-1, 1), want["parts"]["logdet"]) < 1e-4
+
+
+def test_single_direction_jvp_api():
+    g, meta, cfg, dens = build("mini_mnist")
+    head = find_head(dens)
+    z = g["z_low"].cuda()
+    v = torch.randn(z.shape, generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        xh, jv = head.jvp_forward(z, v)
+    want = torch.einsum("bnd,bd->bn", g["J"], v.cpu())
+    assert rel(jv.flatten(1), want) < 1e-4
+    assert rel(xh, g["x_hat"]) < 1e-5
+
+
+def test_bijection_protocol_on_gpu():
+    """x_to_z / z_to_x / jvp of a single coupling layer round-trip and agree with the full Jacobian column."""
+    g, meta, cfg, dens = build("mini_mnist")
+    head = find_head(dens)
+    bij = head.prior.bijection                       # first checkerboard ACL on (1, 28, 28)
+    x = g["head_input"].cuda()
+    with torch.no_grad():
+        r = bij.x_to_z(x)
+        back = bij.z_to_x(r["z"])
+        assert rel(back["x"], x) < 1e-5
+        assert rel(back["log-jac"], -r["log-jac"]) < 1e-4
+        v = torch.randn_like(x)
+        j = bij.jvp(r["z"], v)
+        assert rel(j["x"], x) < 1e-5
+        eps = 1e-2
+        fd = (bij.z_to_x(r["z"] + eps * v)["x"] - bij.z_to_x(r["z"] - eps * v)["x"]) / (2 * eps)
+        assert rel(j["jvp"], fd) < 5e-3
+
+
+def test_cholesky_retry_whole_batch_jitter():
+    """non_square.py:280-288: a singular J^T J anywhere in the batch jitters every sample."""
+    from cmf_amd import engine as E
+    B, N, d = 3, 10, 4
+    gen = torch.Generator().manual_seed(0)
+    J = torch.randn(B, N, 16, generator=gen)
+    J[:, :, d:] = 0
+    J[1, :, 1] = J[1, :, 0]                           # sample 1: two equal columns -> singular Gram
+    T = E.Tangent(B, N, 16, "panel", "cuda", data=J.reshape(-1).cuda())
+    gr = E.gram_cholesky(T, d)
+    fail = gr.fail.tolist()
+    attempts = 1 + next(i for i, f in enumerate(fail) if not f)
+    assert attempts >= 2
+    G = torch.einsum("bni,bnj->bij", J[:, :, :d], J[:, :, :d])
+    added = sum(1e-6 * 10 ** k for k in range(attempts - 1))
+    want = G + added * torch.eye(d)
+    assert torch.allclose(gr.jtj.cpu(), want, rtol=1e-5, atol=1e-6)
+    L = torch.linalg.cholesky(want[[0, 2]].double())
+    ld = 2 * torch.log(torch.diagonal(L, dim1=1, dim2=2)).sum(1)
+    assert torch.allclose(gr.logdet.cpu()[[0, 2]].double(), ld, rtol=1e-4)
+
+
+def test_cpu_tensors_are_refused():
+    g, meta, cfg, dens = build("c1_sphere")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dens.elbo(g["x"])
