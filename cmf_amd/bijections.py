@@ -106,15 +106,14 @@ class AffineCouplingBijection(Bijection):
     def net(self):
         return self.coupler.shift_log_scale_net
 
-    def _set_maps(self, zi, cmod):
-        """zi: flat element ids (in z) of the modified elements, ordered (channel-of-net-output, pixel)."""
+    def _set_maps(self, zi, ti, cmod):
+        """zi: flat element ids (in z) of the modified elements; ti: element of the coupler output (2*cmod
+        channels) holding the shift of each; its log-scale sits cmod channels further (couplers.py:52-59)."""
         HW = self.geom.HW
-        n = len(zi)
-        j = np.arange(n)
         self._maps.put("zi", zi)
-        self._maps.put("ti", j)                 # shift      = first  half of the net's channels (couplers.py:52-59)
-        self._maps.put("si", cmod * HW + j)     # log-scale  = second half
-        self.n_mod, self.cmod = n, cmod
+        self._maps.put("ti", ti)
+        self._maps.put("si", cmod * HW + np.asarray(ti))
+        self.n_mod, self.cmod = len(zi), cmod
 
     def maps(self, device):
         return {"zi": self._maps.get("zi", device), "si": self._maps.get("si", device),
@@ -173,7 +172,8 @@ class Checkerboard2dAffineCouplingBijection(AffineCouplingBijection):
             m = 1 - m
         mask = np.broadcast_to(m, (C, H, W)).copy()
         self.register_buffer("mask", torch.from_numpy(mask))
-        self._set_maps(np.flatnonzero(mask.reshape(-1) == 0), cmod=C)
+        zi = np.flatnonzero(mask.reshape(-1) == 0)
+        self._set_maps(zi, zi, cmod=C)          # the net sees all C channels: its output is indexed like z
 
     def view(self, device):
         return E.NetView(self.geom, cin=self.geom.C, mask=self.mask)
@@ -185,7 +185,7 @@ class _ChannelwiseACL(AffineCouplingBijection):
         super().__init__(x_shape=x_shape, coupler=coupler)
         HW = self.geom.HW
         zi = (np.asarray(mod_idx)[:, None] * HW + np.arange(HW)[None, :]).reshape(-1)
-        self._set_maps(zi, cmod=len(mod_idx))
+        self._set_maps(zi, np.arange(len(zi)), cmod=len(mod_idx))   # net output channel j <-> j-th modified channel
         self._pass = (int(pass_idx[0]), int(pass_idx[1] - pass_idx[0]) if len(pass_idx) > 1 else 1, len(pass_idx))
 
     def view(self, device):

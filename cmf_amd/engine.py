@@ -173,7 +173,7 @@ def acl_tangent(T, YT, z, y, g, maps):
 
 
 class GramResult:
-    __slots__ = ("jtj", "logdet", "l1_off", "l1_diag", "info", "fail")
+    __slots__ = ("jtj", "logdet", "l1_off", "l1_diag", "info", "fail", "attempts")
 
 
 def gram_cholesky(T, d, max_attempts=6, eps0=1e-6):

@@ -16,9 +16,11 @@ SMALL = ["c1_sphere", "c1_sphere_d2", "c2a_power", "c2b_hepmass", "mini_mnist", 
 ALL = SMALL + ["c3_mnist_full"]
 
 
-def rel(a, b):
+def rel(a, b, floor=1e-9):
+    """max |a-b| / max(|b|_max, floor): the floor keeps exact-zero quantities (e.g. the reconstruction error
+    of the square d == D sphere case, ~1e-14 of round-off in both implementations) comparable."""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    return float((a - b).abs().max() / b.abs().max().clamp_min(floor))
 
 
 def build(name):
@@ -147,22 +149,33 @@ def test_single_direction_jvp_api():
 
 
 def test_bijection_protocol_on_gpu():
-    """x_to_z / z_to_x / jvp of a single coupling layer round-trip and agree with the full Jacobian column."""
+    """x_to_z / z_to_x / jvp of single layers: round trip, log-jac sign, tangent vs the oracle's acl_jvp."""
+    from oracle import cmf_oracle as O
     g, meta, cfg, dens = build("mini_mnist")
+    _, schema, x_shape, ops, sd = golden_model(meta)
+    pre, _, flow_ops, base, prior_ops = O.split_ops(ops)
     head = find_head(dens)
-    bij = head.prior.bijection                       # first checkerboard ACL on (1, 28, 28)
-    x = g["head_input"].cuda()
+    x = g["head_input"]
+    node, h = head.prior, x
+    gen = torch.Generator().manual_seed(5)
     with torch.no_grad():
-        r = bij.x_to_z(x)
-        back = bij.z_to_x(r["z"])
-        assert rel(back["x"], x) < 1e-5
-        assert rel(back["log-jac"], -r["log-jac"]) < 1e-4
-        v = torch.randn_like(x)
-        j = bij.jvp(r["z"], v)
-        assert rel(j["x"], x) < 1e-5
-        eps = 1e-2
-        fd = (bij.z_to_x(r["z"] + eps * v)["x"] - bij.z_to_x(r["z"] - eps * v)["x"]) / (2 * eps)
-        assert rel(j["jvp"], fd) < 5e-3
+        for op in flow_ops[:5]:                      # 3 checkerboard ACLs, the squeeze, 1 split-channel ACL
+            bij = node.bijection
+            r = bij.x_to_z(h.cuda())
+            back = bij.z_to_x(r["z"])
+            assert rel(back["x"], h) < 1e-5
+            assert rel(back["log-jac"], -r["log-jac"], floor=1e-3) < 1e-4
+            v = torch.randn(r["z"].shape, generator=gen)
+            j = bij.jvp(r["z"], v.cuda())
+            if op["kind"] == "acl":
+                zr, lj = O.acl_x_to_z(sd, op, h)
+                assert rel(r["z"], zr) < 1e-5 and rel(r["log-jac"], lj, floor=1e-3) < 1e-4
+                xr, jr = O.acl_jvp(sd, op, zr, v)
+                assert rel(j["jvp"], jr) < 1e-4 and rel(j["x"], xr) < 1e-5
+            else:
+                zr = O.squeeze_x_to_z(h, op["factor"])
+                assert rel(r["z"], zr) == 0 and rel(j["jvp"], O.squeeze_z_to_x(v, op["factor"])) == 0
+            h, node = zr, node.prior
 
 
 def test_cholesky_retry_whole_batch_jitter():
