@@ -41,6 +41,35 @@ def ceil16(n):
     return (int(n) + 15) // 16 * 16
 
 
+class KernelTimer:
+    """Optional live timing of one kernel family with HIP events on the launch stream (bench.py's
+    roofline leg).  ``with_events`` brackets a launch with two events; ``summary()`` synchronises once."""
+
+    def __init__(self, select):
+        self.select, self.records = select, []
+
+    def wrap(self, name, work, launch):
+        if not self.select(name):
+            return launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        self.records.append((name, work, e0, e1))
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        n = len(self.records)
+        ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in self.records)
+        return {"launches": n, "total_ms": ms, "work": sum(w for _, w, _, _ in self.records)}
+
+
+TIMER = None   # set to a KernelTimer by bench.py
+
+
 class Tangent:
     """A stack of Jacobian columns attached to a primal tensor of N elements per sample."""
 
@@ -128,7 +157,11 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     a.y = _p(y_t); a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
     a.r = _p(res_t); a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
     a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), int(taps)
-    _lib.check(lib.cmf_conv_tangent(C.byref(a), _stream()), "cmf_conv_tangent")
+    launch = lambda: _lib.check(lib.cmf_conv_tangent(C.byref(a), _stream()), "cmf_conv_tangent")
+    if TIMER is None:
+        return launch()
+    # algorithmic FLOPs of this launch: 2 * cin * cout * taps per output pixel and Jacobian column
+    TIMER.wrap(f"conv_tangent_t{taps}_ci{cin}_co{cout}", 2.0 * cin * cout * taps * H * W * nc * np_, launch)
 
 
 def gather_primal(src, idx, n_out, out=None):
