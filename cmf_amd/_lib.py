@@ -56,7 +56,7 @@ SIGNATURES = {
     "cmf_affine_prior": (_i, [_fp, _ll, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "cmf_recon_sqerr": (_i, [_fp, _fp, _i, _i, _fp, _fp]),
     "cmf_elbo_combine": (_i, [_fp, _fp, _fp, _fp, _fp, _f, _f, _f, _i, _fp, _fp]),
-    "cmf_hutch_value": (_i, [_fp, _fp, _i, _i, _i, _fp, _fp]),
+    "cmf_hutch_cg": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _fp, _fp]),
 }
 
 _lib = None

@@ -210,17 +210,6 @@ __global__ void elbo_combine_kernel(const float* low, const float* logdet, const
   elbo[b] = v;
 }
 
-__global__ void hutch_value_kernel(const float* __restrict__ u, const float* __restrict__ w, int d, int S, int B,
-                                   float* __restrict__ val) {
-  const int b = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (b >= B) return;
-  float acc = 0.f;
-  const long long base = (long long)b * d * S;
-  for (int i = lane; i < d * S; i += 64) acc += u[base + i] * w[base + i];
-  acc = wave_sum(acc);
-  if (lane == 0) val[b] = acc / (float)S;
-}
-
 }  // namespace
 
 extern "C" {
@@ -345,13 +334,6 @@ int cmf_elbo_combine(const float* low, const float* logdet, const float* rec, co
   if (!elbo || B <= 0) return CMF_EINVAL;
   hipLaunchKernelGGL(elbo_combine_kernel, dim3(nblocks(B)), dim3(TPB), 0, (hipStream_t)stream, low, logdet, rec, l1, pre,
                      wl, lam, wm, B, elbo);
-  CMF_LAUNCH_CHECK();
-  return 0;
-}
-
-int cmf_hutch_value(const float* u, const float* w, int d, int S, int B, float* val, void* stream) {
-  if (!u || !w || !val || d <= 0 || S <= 0 || B <= 0) return CMF_EINVAL;
-  hipLaunchKernelGGL(hutch_value_kernel, dim3((B + 3) / 4), dim3(TPB), 0, (hipStream_t)stream, u, w, d, S, B, val);
   CMF_LAUNCH_CHECK();
   return 0;
 }

@@ -496,16 +496,24 @@ class NonSquareHeadDensity(Density):
         z_low, low_elbo, _ = prog.encode(x)
         logdet = l1 = None
         if want_jac:
-            if self.training and self.log_jacobian_method == "hutch_with_cg":
-                raise NotImplementedError(
-                    "train-mode Hutchinson+CG surrogate (non_square.py:203-258) needs the reverse-mode sweep "
-                    "(SURVEY.md a14/f1); eval mode uses the exact path like the reference (:133)")
             x_hat, T = prog.decode(z_low, tangents=True)
             g = E.gram_cholesky(T, prog.d, self.MAX_ATTEMPTS)
             self.last_gram = g
-            self._report_attempts(g)
-            logdet = g.logdet
-            l1 = g.l1_diag if add_diag else (g.l1_off if add_off else None)
+            if self.training and self.log_jacobian_method == "hutch_with_cg":
+                # train mode: Hutchinson + CG surrogate (non_square.py:131-138, :203-258) on the explicit Gram matrix
+                if add_diag or add_off:
+                    if self.num_hutchinson_samples != prog.d:
+                        raise ValueError("metric regularisation with hutch_with_cg needs num_hutchinson_samples == "
+                                         "latent_dimension (the reference fails at non_square.py:98 otherwise)")
+                    raise NotImplementedError("g-term on the (B, d, S) Hutchinson product is not built")
+                eps = self._hutchinson_probes(B, dev)
+                val, u, w, iters = E.hutch_cg(g.jtj, eps, self.max_cg_iterations or prog.d, self.cg_tolerance)
+                self.last_hutchinson = {"eps": eps, "u": u, "w": w, "iterations": iters, "value": val}
+                logdet = val
+            else:
+                self._report_attempts(g)
+                logdet = g.logdet
+                l1 = g.l1_diag if add_diag else (g.l1_off if add_off else None)
         else:
             x_hat, _ = prog.decode(z_low, tangents=False)      # warm-up: decode only (non_square.py:105-109)
         rec = E.recon_sqerr(x_hat, x) if add_rec else None
@@ -515,6 +523,15 @@ class NonSquareHeadDensity(Density):
         elbo = E.elbo_combine(low_elbo if want_lik else None, logdet, rec, l1, pre, lw, self.regularization_param, mw,
                               B, dev)
         return {"elbo": elbo, "prior-dict": {"elbo": low_elbo.view(B, 1), "low-dim-x": z_low}}
+
+    def _hutchinson_probes(self, B, dev):
+        """non_square.py:204-213: N(0,1) or Rademacher probes of shape (B, d, S)."""
+        shape = (B, self.program.d, self.num_hutchinson_samples)
+        if self.hutchinson_distribution == "normal":
+            return torch.randn(*shape, device=dev)
+        if self.hutchinson_distribution == "rademacher":
+            return torch.bernoulli(0.5 * torch.ones(*shape, device=dev)).mul_(2.).subtract_(1.)
+        raise ValueError(f"Unknown hutchinson distribution {self.hutchinson_distribution}")
 
     def _report_attempts(self, g):
         if self.check_cholesky != "sync":

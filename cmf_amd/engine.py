@@ -103,15 +103,20 @@ class Tangent:
 
 
 class _PackCache:
+    """Packed (kernel-layout) copies of weights, rebuilt when the parameter is updated in place
+    (``_version``), re-allocated or moved.  Entries hold a weak reference to the parameter and are
+    validated by identity: ``id()`` values and device addresses are recycled after garbage collection."""
+
     def __init__(self):
         self._store = {}
 
     def get(self, weight, taps, transpose=False):
+        import weakref
         key = (id(weight), bool(transpose))
-        ver = (weight._version, weight.data_ptr(), weight.device)
+        ver = (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape))
         hit = self._store.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
+        if hit is not None and hit[0]() is weight and hit[1] == ver:
+            return hit[2]
         lib = _lib.load()
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
         n = C.c_longlong(0)
@@ -119,7 +124,9 @@ class _PackCache:
         out = torch.empty(n.value, dtype=torch.float32, device=weight.device)
         w = weight.detach().contiguous()
         _lib.check(lib.cmf_pack_weight(_p(w), _p(out), cout, cin, taps, int(transpose), None, _stream()), "cmf_pack_weight")
-        self._store[key] = (ver, out)
+        if len(self._store) > 4096:                                   # drop entries whose parameter is gone
+            self._store = {k: v for k, v in self._store.items() if v[0]() is not None}
+        self._store[key] = (weakref.ref(weight), ver, out)
         return out
 
 
@@ -226,6 +233,20 @@ def gram_cholesky(T, d, max_attempts=6, eps0=1e-6):
         _lib.check(lib.cmf_cholesky_retry(_p(r.jtj), d, T.B, a, eps0, _p(r.logdet), _p(r.l1_diag), _p(r.info), _p(r.fail),
                                           _stream()), "cmf_cholesky_retry")
     return r
+
+
+def hutch_cg(jtj, eps, max_iter, tol, min_iter=None):
+    """Hutchinson surrogate on explicit J^T J: returns (value (B,), u, w (B,d,S), iterations (B,))."""
+    B, d, S = eps.shape
+    if min_iter is None:
+        min_iter = min(10, max_iter - 1) + 1 if max_iter > 1 else 1
+    dev = eps.device
+    u, w = torch.empty_like(eps), torch.empty_like(eps)
+    val = torch.empty(B, dtype=torch.float32, device=dev)
+    iters = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().cmf_hutch_cg(_p(jtj), _p(eps.contiguous()), d, S, B, int(max_iter), int(min_iter), float(tol),
+                                        _p(u), _p(w), _p(val), _p(iters), _stream()), "cmf_hutch_cg")
+    return val, u, w, iters
 
 
 def prehead(x, noise, a, c, logit):

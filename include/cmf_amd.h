@@ -159,10 +159,14 @@ int cmf_recon_sqerr(const float* xh, const float* x, int n, int B, float* rec, v
  * (non_square.py:85, :126-129 and exact.py:27 for the pre-head log-jacobians)                      */
 int cmf_elbo_combine(const float* low, const float* logdet, const float* rec, const float* l1, const float* pre,
                      float wl, float lam, float wm, int B, float* elbo, void* stream);
-/* Hutchinson pieces (non_square.py:190-201, :232-256).  w(b, :, s) = J(b)^T u(b) for S probe columns:
- * w[b][k][s] = sum_r T(b, r, k) * U(b, r, s) with T the full d-column Jacobian panel (exact J^T J eps);
- * the matrix-free form runs cmf_conv_tangent with transposed packs instead.        */
-int cmf_hutch_value(const float* u, const float* w, int d, int S, int B, float* val, void* stream);
+/* Hutchinson log-det surrogate (non_square.py:203-258) against the EXPLICIT Gram matrix produced by
+ * cmf_gram_cholesky (see hutch_cg.hip for why the explicit form is the cheaper one on this hardware):
+ *   w(b,:,s) = G(b) eps(b,:,s);  u = CG(G, eps) with x0 = 0, unit-normalised right-hand sides, at least
+ *   min_iter and at most max_iter iterations, stopping a sample when the mean over its S probes of the
+ *   relative residual 2-norm drops below tol;  val[b] = mean_s sum_k u*w.   eps, u, w: [B][d][S]; S <= 16.
+ * The reference's solver (gpytorch linear_cg @ fc2053b) is un-vendored: CG iterates are parity-unpinned. */
+int cmf_hutch_cg(const float* jtj, const float* eps, int d, int S, int B, int max_iter, int min_iter, float tol,
+                 float* u, float* w, float* val, int* iters, void* stream);
 
 #ifdef __cplusplus
 }

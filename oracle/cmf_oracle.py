@@ -610,3 +610,34 @@ def hutchinson_surrogate(sd, ops, z_low, eps, solve="exact"):
     jtj, _, _ = jtj_batched(sd, flow_ops, base, z_low)
     u = torch.linalg.solve(jtj, eps)
     return (u * w).sum(1, keepdim=True).mean(2), xh, w
+
+
+def cg_documented(jtj, eps, max_iter, tol, min_iter=None):
+    """The build's own CG stopping rule (cmf_amd/csrc/hutch_cg.hip), restated for checking the kernel:
+    x0 = 0, unit-normalised right-hand sides, stop a sample after iteration k >= min_iter once the mean over its
+    probes of the relative residual norm is < tol; at most max_iter.  (gpytorch's linear_cg @ fc2053b, which the
+    reference calls at non_square.py:241-247, is un-vendored: parity unpinned.)"""
+    B, d, S = eps.shape
+    if min_iter is None:
+        min_iter = min(10, max_iter - 1) + 1 if max_iter > 1 else 1
+    nb = eps.norm(dim=1, keepdim=True)
+    r = eps / nb
+    x, p = torch.zeros_like(r), r.clone()
+    rr = (r * r).sum(1, keepdim=True)
+    active = torch.ones(B, dtype=torch.bool)
+    iters = torch.zeros(B, dtype=torch.int32)
+    for k in range(1, max_iter + 1):
+        q = torch.bmm(jtj, p)
+        alpha = rr / (p * q).sum(1, keepdim=True)
+        a = active.view(B, 1, 1)
+        x = torch.where(a, x + alpha * p, x)
+        r_new = r - alpha * q
+        rr_new = (r_new * r_new).sum(1, keepdim=True)
+        p = torch.where(a, r_new + (rr_new / rr) * p, p)
+        r, rr = torch.where(a, r_new, r), torch.where(a, rr_new, rr)
+        iters[active] = k
+        done = (k >= min_iter) & (rr.sqrt().mean(2).squeeze(1) < tol)
+        active = active & ~done
+        if not active.any():
+            break
+    return x * nb, iters

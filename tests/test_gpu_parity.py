@@ -204,3 +204,47 @@ def test_cpu_tensors_are_refused():
     g, meta, cfg, dens = build("c1_sphere")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         dens.elbo(g["x"])
+
+
+@pytest.mark.parametrize("name", ["c1_sphere", "c2b_hepmass", "mini_mnist", "mini_cifar"])
+def test_hutchinson_surrogate(name):
+    """Row a14: J^T J eps is pinned by the reference vectors; the CG iterates follow the build's documented rule
+    (gpytorch's solver is un-vendored) and are checked against its CPU restatement and the exact solve."""
+    from cmf_amd import engine as E
+    from oracle import cmf_oracle as O
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    eps = g["hutch_eps"].cuda()
+    d = eps.shape[1]
+    with torch.no_grad():
+        x_hat, T = head.program.decode(g["z_low"].cuda(), tangents=True)
+        gr = E.gram_cholesky(T, d)
+        val, u, w, iters = E.hutch_cg(gr.jtj, eps, max_iter=4 * d, tol=1e-7, min_iter=1)       # run to convergence
+        assert rel(w, g["hutch_jtj_eps"]) < 1e-4                                                # pinned by the reference
+        exact = torch.linalg.solve(g["jtj"].double(), g["hutch_eps"].double())
+        assert rel(u, exact) < 1e-3
+        assert rel(val, (g["hutch_eps"] ** 2).sum(1).mean(1)) < 1e-3                           # SURVEY fact 8(ii)
+        for max_iter in (1, 2, 5):
+            val2, u2, w2, it2 = E.hutch_cg(gr.jtj, eps, max_iter=max_iter, tol=1.0)
+            uo, ito = O.cg_documented(g["jtj"], g["hutch_eps"], max_iter, 1.0)
+            assert it2.cpu().tolist() == ito.tolist()
+            assert rel(u2, uo) < 1e-4
+
+
+def test_train_mode_hutchinson_elbo():
+    g, meta, cfg, dens = build("mini_mnist")
+    head = find_head(dens)
+    head.log_jacobian_method, head.num_hutchinson_samples, head.max_cg_iterations = "hutch_with_cg", 3, 4
+    x = (g["x"] + g["noise"]).cuda()
+    with torch.no_grad():
+        dens.train()
+        out = inner(dens, True).elbo(x, add_reconstruction=True)
+        h = head.last_hutchinson
+        assert h["w"].shape == (3, 4, 3) and torch.isfinite(out["elbo"]).all()
+        want = g["low_dim_elbo"] - h["value"].cpu().view(-1, 1) / 2 - 50 * g["ood_recon"] + g["prehead_logjac"]
+        assert rel(out["elbo"], want) < 1e-4
+        with pytest.raises(ValueError):
+            inner(dens, True).elbo(x, add_offdiagonal_metric_reg=True)
+        dens.eval()                                   # eval always takes the exact path (non_square.py:133)
+        out = inner(dens, True).elbo(x, add_reconstruction=True, add_offdiagonal_metric_reg=True)
+        assert rel(out["elbo"], g["elbo_0"]) < 1e-4
