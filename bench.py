@@ -26,6 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA
+HBM_PEAK_GBS = 8000.0                  # HBM3E spec (6.3 TB/s measured achievable)
 
 
 def make_model(device, d=64, hidden=(64,) * 8, dataset="mnist", seed=0):
@@ -67,6 +69,16 @@ def cpu_baseline(schema, shape, sd, B_cpu):
                       f"oracle.jtj_ref_equivalent (column loop + primal recompute = what the reference executes)"}
 
 
+def pmc_traffic(precision):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
+    command (profiles/*_pmc_*.json; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction), or None."""
+    path = os.path.join(ROOT, "profiles", f"pmc_conv_tangent_{precision}.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("traffic_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +88,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="shard a fixed global batch over the ranks")
     ap.add_argument("--cpu-batch", type=int, default=16, help="CPU baseline sample size (0 disables)")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
+                    help="arithmetic of the 3x3 tangent convolutions (both are fp32-grade; see DESIGN.md 4.5)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -91,6 +105,7 @@ def main():
 
     from cmf_amd import engine as E
     from cmf_amd.distributed import allreduce_mean_elbo
+    E.TANGENT_PRECISION = args.precision
     cfg, schema, shape, sd, density = make_model(device)
     inner = density.module.density                       # feed dequantised data ourselves: noise is part of the synthetic input
     B = args.batch // world if args.strong else args.batch
@@ -131,19 +146,34 @@ def main():
             "metric": "log-density evals/sec (JtJ-cholesky path), MNIST D=784 d=64 bs=512",
             "value": total / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "f32 (3x3 tangent convs as bf16x3 split MFMA, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "C3: MNIST-shaped (1,28,28) uint8-range + U[0,1) noise, non-square flow d=64, "
                                    "cholesky J^T J log-det + g_ij off-diagonal L1 + reconstruction, eval/no_grad",
                        "per_gpu_batch": B, "global_batch": B * world, "D": 784, "latent_dimension": 64,
                        "parallelism": f"dp{world}", "loss_mean": float(loss)},
         }
         if ksum and ksum["launches"]:
-            ach = ksum["work"] / (ksum["total_ms"] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                                "kernel": "conv_tangent_kernel<9,4,7> (3x3, 64->64 channels, all d Jacobian columns)",
-                                "launches": ksum["launches"], "avg_ms": ksum["total_ms"] / ksum["launches"],
-                                "share_of_step": ksum["total_ms"] / (1e3 * dt)}
+            sec = ksum["total_ms"] * 1e-3
+            tf, gbs = ksum["flops"] / sec / 1e12, ksum["bytes"] / sec / 1e9
+            common = {"launches": ksum["launches"], "avg_ms": ksum["total_ms"] / ksum["launches"],
+                      "share_of_step": ksum["total_ms"] / (1e3 * dt), "traffic": pmc_traffic(E.TANGENT_PRECISION),
+                      "algorithmic_tflops": tf, "algorithmic_gbs": gbs}
+            if E.TANGENT_PRECISION == "bf16x3":
+                # 3 bf16 MFMAs per fp32-grade product (+25 % K padding): at this speed the kernel moves its
+                # algorithmic bytes at about half of HBM peak and that, not the matrix pipe, is the bound to chase
+                line["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": gbs / HBM_PEAK_GBS,
+                                    "kernel": "conv_tangent_bf16x3_kernel<4,7> (3x3, 64->64 channels, all d Jacobian columns; "
+                                              "split-precision bf16 MFMA, fp32 accumulate)",
+                                    "mfma_view": {"fp32_equivalent_tflops": tf, "executed_bf16_tflops": 4.0 * tf,
+                                                  "frac_of_bf16_peak": 4.0 * tf / BF16_MFMA_PEAK_TFLOPS}, **common}
+            else:
+                line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                                    "kernel": "conv_tangent_kernel<9,4,7> (3x3, 64->64 channels, all d Jacobian columns; fp32 MFMA)",
+                                    **common}
         if world == 1 and args.cpu_batch > 0:
             line["cpu_baseline"] = cpu_baseline(schema, shape, {k: v.cpu() for k, v in sd.items()}, args.cpu_batch)
         print(json.dumps(line))

@@ -42,6 +42,8 @@ SIGNATURES = {
     "cmf_version": (C.c_char_p, []),
     "cmf_pack_weight": (_i, [_fp, _fp, _i, _i, _i, _i, C.POINTER(_ll), _fp]),
     "cmf_conv_tangent": (_i, [C.POINTER(ConvTangentArgs), _fp]),
+    "cmf_pack_weight_bf16x3": (_i, [_fp, _fp, _i, _i, C.POINTER(_ll), _fp]),
+    "cmf_conv_tangent_bf16x3": (_i, [C.POINTER(ConvTangentArgs), _fp]),
     "cmf_conv_primal": (_i, [C.POINTER(ConvPrimalArgs), _fp]),
     "cmf_acl_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "cmf_acl_tangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _fp]),

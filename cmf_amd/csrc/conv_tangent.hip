@@ -42,8 +42,8 @@ struct Cfg {
 };
 
 template <int TAPS, int COT, int PXW>
-__global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_args a, int tiles_x, int nslices,
-                                                                int cin_pad) {
+__global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
+                                                                int nslices, int ncog, int cin_pad) {
   using C = Cfg<TAPS, COT, PXW>;
   __shared__ __attribute__((aligned(16))) float smem[C::XS_FLOATS + C::WS_FLOATS];
   float* Xs = smem;
@@ -54,10 +54,24 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, cl = lane & 15;
 
-  const int tile = blockIdx.x;
-  const int slice = blockIdx.y % nslices;
-  const int cog = blockIdx.y / nslices;
-  const int np = blockIdx.z;
+  // XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so
+  // with the natural order the 16-column slices of one 128-byte line and the overlapping halos of adjacent
+  // pixel tiles would be fetched by different L2s (measured: FETCH_SIZE 3-5x the algorithmic bytes).  Remap
+  // so that XCD k works through a contiguous range of logical ids, ordered slice-fastest, then tile, then
+  // sample: concurrently resident workgroups of an XCD then share lines and halos in its L2.  Bijective for
+  // any grid size (cdna_hip_programming.md section 5, XCD swizzle); affects speed only, never results.
+  int tile, slice, cog, np;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    slice = w % nslices;
+    w /= nslices;
+    tile = w % ntiles;
+    w /= ntiles;
+    cog = w % ncog;
+    np = w / ncog;
+  }
   const int HW = a.H * a.W;
 
   int y0 = 0, x0 = 0, p0 = 0;
@@ -261,8 +275,10 @@ int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   }
   const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
   const int cin_pad = (a.cin + 7) / 8 * 8;
-  dim3 grid(tiles, nslices * ncog, a.np);
-  hipLaunchKernelGGL((conv_tangent_kernel<TAPS, COT, PXW>), grid, dim3(256), 0, s, a, tiles_x, nslices, cin_pad);
+  const long long total = (long long)tiles * nslices * ncog * a.np;
+  if (total > 0x7fffffffLL) return CMF_ERANGE;
+  hipLaunchKernelGGL((conv_tangent_kernel<TAPS, COT, PXW>), dim3((unsigned)total), dim3(256), 0, s, a, tiles_x, tiles,
+                     nslices, ncog, cin_pad);
   CMF_LAUNCH_CHECK();
   return 0;
 }
@@ -295,7 +311,7 @@ extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
   // per-sample offsets are held in 32-bit registers
   if (!fits_int((a.cin + 8) * a.x_ci + HW * a.x_px + a.nc) || !fits_int((a.cin + 8) * a.f_ci + HW * a.f_px) ||
       !fits_int((a.cout + 64) * a.y_co + HW * a.y_px + a.nc) || (a.r && !fits_int((a.cout + 64) * a.r_co + HW * a.r_px + a.nc)) ||
-      a.np > 65535 || HW > (1 << 24))
+      HW > (1 << 24))
     return CMF_ERANGE;
   hipStream_t s = (hipStream_t)stream;
   const bool seven = (a.taps == 9) ? (a.W % 14 == 0) : (HW % 28 == 0 && HW % 32 != 0);

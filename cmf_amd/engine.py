@@ -48,14 +48,14 @@ class KernelTimer:
     def __init__(self, select):
         self.select, self.records = select, []
 
-    def wrap(self, name, work, launch):
+    def wrap(self, name, flops, nbytes, launch):
         if not self.select(name):
             return launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()
         e1.record()
-        self.records.append((name, work, e0, e1))
+        self.records.append((name, flops, nbytes, e0, e1))
 
     def reset(self):
         self.records = []
@@ -63,11 +63,21 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         n = len(self.records)
-        ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in self.records)
-        return {"launches": n, "total_ms": ms, "work": sum(w for _, w, _, _ in self.records)}
+        ms = sum(r[3].elapsed_time(r[4]) for r in self.records)
+        return {"launches": n, "total_ms": ms, "flops": sum(r[1] for r in self.records),
+                "bytes": sum(r[2] for r in self.records)}
 
 
 TIMER = None   # set to a KernelTimer by bench.py
+
+#: arithmetic of the 3x3 tangent convolutions: "bf16x3" = split-precision bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32
+#: accumulate; fp32-grade result), "f32" = exact fp32 MFMA.  Layers the bf16x3 kernel does not cover
+#: (1x1, cin % 8 != 0, widths other than 14 / 28) always use the fp32 kernel.
+TANGENT_PRECISION = "bf16x3"
+
+
+def _use_bf16x3(taps, cin, W, transpose):
+    return TANGENT_PRECISION == "bf16x3" and taps == 9 and cin % 8 == 0 and W % 14 == 0 and not transpose
 
 
 class Tangent:
@@ -110,9 +120,9 @@ class _PackCache:
     def __init__(self):
         self._store = {}
 
-    def get(self, weight, taps, transpose=False):
+    def get(self, weight, taps, transpose=False, bf16x3=False):
         import weakref
-        key = (id(weight), bool(transpose))
+        key = (id(weight), bool(transpose), bool(bf16x3))
         ver = (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape))
         hit = self._store.get(key)
         if hit is not None and hit[0]() is weight and hit[1] == ver:
@@ -120,10 +130,15 @@ class _PackCache:
         lib = _lib.load()
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
         n = C.c_longlong(0)
-        _lib.check(lib.cmf_pack_weight(None, None, cout, cin, taps, int(transpose), C.byref(n), None), "pack size")
-        out = torch.empty(n.value, dtype=torch.float32, device=weight.device)
         w = weight.detach().contiguous()
-        _lib.check(lib.cmf_pack_weight(_p(w), _p(out), cout, cin, taps, int(transpose), None, _stream()), "cmf_pack_weight")
+        if bf16x3:
+            _lib.check(lib.cmf_pack_weight_bf16x3(None, None, cout, cin, C.byref(n), None), "pack size")
+            out = torch.empty(n.value, dtype=torch.uint8, device=weight.device)
+            _lib.check(lib.cmf_pack_weight_bf16x3(_p(w), _p(out), cout, cin, None, _stream()), "cmf_pack_weight_bf16x3")
+        else:
+            _lib.check(lib.cmf_pack_weight(None, None, cout, cin, taps, int(transpose), C.byref(n), None), "pack size")
+            out = torch.empty(n.value, dtype=torch.float32, device=weight.device)
+            _lib.check(lib.cmf_pack_weight(_p(w), _p(out), cout, cin, taps, int(transpose), None, _stream()), "cmf_pack_weight")
         if len(self._store) > 4096:                                   # drop entries whose parameter is gone
             self._store = {k: v for k, v in self._store.items() if v[0]() is not None}
         self._store[key] = (weakref.ref(weight), ver, out)
@@ -160,15 +175,20 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     a = ConvTangentArgs()
     a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
     a.f = _p(f); a.f_np, a.f_ci, a.f_px = int(f_np), int(f_ci), int(f_px); a.fmode = fmode
-    a.w = _p(PACKS.get(weight, taps, transpose))
+    split = _use_bf16x3(taps, cin, W, transpose)
+    a.w = _p(PACKS.get(weight, taps, transpose, bf16x3=split))
     a.y = _p(y_t); a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
     a.r = _p(res_t); a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
     a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), int(taps)
-    launch = lambda: _lib.check(lib.cmf_conv_tangent(C.byref(a), _stream()), "cmf_conv_tangent")
+    fn, what = (lib.cmf_conv_tangent_bf16x3, "cmf_conv_tangent_bf16x3") if split else (lib.cmf_conv_tangent, "cmf_conv_tangent")
+    launch = lambda: _lib.check(fn(C.byref(a), _stream()), what)
     if TIMER is None:
         return launch()
-    # algorithmic FLOPs of this launch: 2 * cin * cout * taps per output pixel and Jacobian column
-    TIMER.wrap(f"conv_tangent_t{taps}_ci{cin}_co{cout}", 2.0 * cin * cout * taps * H * W * nc * np_, launch)
+    # algorithmic work of this launch: 2*cin*cout*taps FLOP per output pixel and Jacobian column; every input,
+    # output and residual element crosses HBM once (4 bytes each)
+    px = float(H) * W * nc * np_
+    TIMER.wrap(f"conv_tangent_t{taps}_ci{cin}_co{cout}", 2.0 * cin * cout * taps * px,
+               4.0 * px * (cin + cout + (cout if res_t is not None else 0)), launch)
 
 
 def gather_primal(src, idx, n_out, out=None):

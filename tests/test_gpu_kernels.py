@@ -13,11 +13,15 @@ def rel(a, b):
 
 @pytest.mark.parametrize("cin,cout,H,W,taps,nc", [
     (64, 64, 14, 14, 9, 64), (64, 64, 28, 28, 9, 32), (2, 64, 14, 14, 9, 16), (64, 4, 14, 14, 1, 64),
-    (64, 64, 16, 16, 9, 16), (3, 24, 9, 11, 9, 16), (17, 40, 5, 7, 9, 32), (64, 2, 28, 28, 1, 16), (130, 70, 1, 37, 1, 16),
+    (64, 64, 16, 16, 9, 16), (3, 24, 9, 11, 9, 16), (8, 64, 14, 14, 9, 16), (16, 40, 5, 28, 9, 32), (64, 130, 3, 14, 9, 16), (17, 40, 5, 7, 9, 32), (64, 2, 28, 28, 1, 16), (130, 70, 1, 37, 1, 16),
 ])
 @pytest.mark.parametrize("fmode", ["none", "relu", "tanh", "raw"])
-def test_conv_tangent(cin, cout, H, W, taps, nc, fmode):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, monkeypatch):
     from cmf_amd import engine as E
+    monkeypatch.setattr(E, "TANGENT_PRECISION", precision)
+    if precision == "bf16x3" and not E._use_bf16x3(taps, cin, W, False):
+        pytest.skip("shape not covered by the split-precision kernel (falls back to fp32)")
     gen = torch.Generator().manual_seed(cin * 1000 + cout + H)
     B = 3
     w = torch.randn(cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1, generator=gen) / (cin * taps) ** 0.5
@@ -35,6 +39,7 @@ def test_conv_tangent(cin, cout, H, W, taps, nc, fmode):
     E.conv_tangent(x.cuda(), 0, cin * HW * nc, HW * nc, nc, wd, taps, y, cout * HW * nc, HW * nc, nc, B, cin, cout, H, W, nc,
                    fmode={"none": E.F_NONE, "relu": E.F_RELU, "tanh": E.F_TANH, "raw": E.F_RAW}[fmode],
                    f=None if src is None else src.cuda(), f_np=cin * HW, f_ci=HW, f_px=1, res_t=res.cuda())
+    # bf16x3: ~2^-16 per product, well inside the same bound as the fp32 kernel for these K sizes
     assert rel(y, want) < 2e-5
 
 
