@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
   // factor at commit time): a conditional load makes hipcc branch and drain vmcnt per item.
   const int x_ci = (int)a.x_ci, x_px = (int)a.x_px, f_ci = (int)a.f_ci, f_px = (int)a.f_px;
   int xo[C::NXIT], fo[C::NXIT];
-  unsigned okbits = 0;
+  unsigned okbits = 0;                   // validity per item; applied arithmetically at commit time
 #pragma unroll
   for (int it = 0; it < C::NXIT; ++it) {
     const int i = tid + 256 * it;
@@ -108,27 +108,40 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
       gpix = p0 + pix;
       ok = ok && gpix < HW;
     }
-    xo[it] = ok ? ci * x_ci + gpix * x_px + q * 4 : 0;
-    fo[it] = ok ? ci * f_ci + gpix * f_px : 0;
+    xo[it] = ok ? 4 * (ci * x_ci + gpix * x_px + q * 4) : 0;     // BYTE offsets against wave-uniform bases
+    fo[it] = ok ? 4 * (ci * f_ci + gpix * f_px) : 0;
     okbits |= (ok ? 1u : 0u) << it;
   }
 
   f32x4 xr[C::NXIT];
   float fr[C::NXIT];
   f32x4 wr[C::NWIT];
-  const float fzero = (a.fmode == CMF_F_TANH) ? 1.f : 0.f;   // factor source value that yields multiplier 0
+#pragma unroll
+  for (int it = 0; it < C::NXIT; ++it) fr[it] = 0.f;   // stays 0 when fmode == NONE (never loaded)
+  // NONE: 1   RELU: [f>0]   TANH: 1 - f^2   RAW: f
+  const float fc0 = (a.fmode == CMF_F_NONE || a.fmode == CMF_F_TANH) ? 1.f : 0.f;
+  const float fc1 = (a.fmode == CMF_F_RELU) ? 1.f : 0.f;
+  const float fc2 = (a.fmode == CMF_F_RAW) ? 1.f : 0.f;
+  const float fc3 = (a.fmode == CMF_F_TANH) ? -1.f : 0.f;
+  unsigned okchunk = 0;                  // okbits restricted to channels < cin for the chunk being prefetched
 
+  // Loads are unconditional and always consumed (a select on validity lets hipcc sink a load into a branch +
+  // s_waitcnt vmcnt(0), serialising the prefetch); invalid items read element 0 and get multiplier 0 at commit.
   auto prefetch = [&](int ci0) {
+    okchunk = 0;
 #pragma unroll
     for (int it = 0; it < C::NXIT; ++it) {
       const int ci = ((tid + 256 * it) >> 2) / C::PIXH;
       const bool ok = ((okbits >> it) & 1u) && (ci0 + ci) < a.cin;
-      xr[it] = *reinterpret_cast<const f32x4*>(xb + (ok ? ci0 * x_ci + xo[it] : 0));
-      if (a.fmode != CMF_F_NONE) {
-        const float fv = fb[ok ? ci0 * f_ci + fo[it] : 0];
-        fr[it] = ok ? fv : fzero;
-      } else {
-        fr[it] = ok ? 1.f : 0.f;
+      okchunk |= (ok ? 1u : 0u) << it;
+      const unsigned off = ok ? 4u * (unsigned)(ci0 * x_ci) + (unsigned)xo[it] : 0u;
+      xr[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(xb) + off);
+    }
+    if (a.fmode != CMF_F_NONE) {
+#pragma unroll
+      for (int it = 0; it < C::NXIT; ++it) {
+        const unsigned off = ((okchunk >> it) & 1u) ? 4u * (unsigned)(ci0 * f_ci) + (unsigned)fo[it] : 0u;
+        fr[it] = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(fb) + off);
       }
     }
 #pragma unroll
@@ -137,20 +150,22 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
       i = i < C::NW_ITEMS ? i : C::NW_ITEMS - 1;
       const int q = i % (COT * 4), rowi = i / (COT * 4);
       const int ci = rowi % CIC, tap = rowi / CIC;
-      wr[it] = *reinterpret_cast<const f32x4*>(wb + (tap * cin_pad + ci0 + ci) * 64 + q * 4);
+      const unsigned off = 4u * (unsigned)((tap * cin_pad + ci0 + ci) * 64 + q * 4);
+      wr[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(wb) + off);
     }
   };
 
   auto commit = [&]() {
+    const unsigned okcommit = okchunk;   // validity of the chunk whose registers are being committed
 #pragma unroll
     for (int it = 0; it < C::NXIT; ++it) {
       const int i = tid + 256 * it;
       if (i < C::NX_ITEMS) {
         const int q = i & 3, rowi = i >> 2;
         const int pix = rowi % C::PIXH, ci = rowi / C::PIXH;
-        float m = fr[it];
-        if (a.fmode == CMF_F_RELU) m = m > 0.f ? 1.f : 0.f;
-        else if (a.fmode == CMF_F_TANH) m = 1.f - m * m;
+        // branch-free multiplier: ok * (c0 + c1*[f>0] + c2*f + c3*f*f) with wave-uniform mode coefficients
+        const float f = fr[it];
+        const float m = (((okcommit >> it) & 1u) ? 1.f : 0.f) * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
         *reinterpret_cast<f32x4*>(Xs + ci * C::XS_CI + pix * 16 + q * 4) = xr[it] * m;
       }
     }
@@ -294,7 +309,7 @@ int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
   }
 }
 
-inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 31); }
+inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 29); }   // element offsets; x4 bytes must fit 32 bits
 
 }  // namespace
 

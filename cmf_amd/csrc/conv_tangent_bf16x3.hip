@@ -22,6 +22,24 @@
 #include <type_traits>
 #include "common.h"
 
+#ifdef CMF_DBG_STAMP
+// diagnostic build only: phase timestamps of workgroup 0 (wave 0 = MFMA role, wave 4 = loader role)
+__device__ unsigned long long cmf_dbg_stamps[2][64][4];
+extern "C" int cmf_debug_read_stamps(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cmf_dbg_stamps), sizeof(cmf_dbg_stamps));
+}
+#define STAMP(role, g, k)                                                                        \
+  do {                                                                                            \
+    if (blockIdx.x == 0 && (g) < 64 && lane == 0 && wave == ((role) ? 4 : 0)) {                   \
+      unsigned long long t_;                                                                      \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+      cmf_dbg_stamps[role][g][k] = t_;                                                            \
+    }                                                                                             \
+  } while (0)
+#else
+#define STAMP(role, g, k) do {} while (0)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -34,11 +52,12 @@ struct BCfg {
   static constexpr int TW = 2 * PXW, TWH = TW + 2, PIXH = 4 * TWH;
   static constexpr int XS_BYTES = PIXH * 16 * 16;                 // one of hi / lo
   static constexpr int WS_BYTES = 3 * COT * 4 * 16 * 16;          // one of hi / lo
+  static constexpr int BUF_BYTES = 2 * XS_BYTES + 2 * WS_BYTES;   // one pipeline stage
   static constexpr int W_CHUNK_BYTES = 2 * 3 * 4 * 4 * 16 * 16;   // global: [hl][s][cot 4][kq][co][8] bf16 = 24 KiB
-  static constexpr int NX_ITEMS = PIXH * 4;                       // (pixel, column quad)
-  static constexpr int NXIT = (NX_ITEMS + 255) / 256;
+  static constexpr int NX_ITEMS = PIXH * 4;                       // (pixel, column quad): one per loader thread
   static constexpr int NW_ITEMS = 2 * 3 * COT * 4 * 16;           // 16-byte items of the W chunk actually used
   static constexpr int NWIT = (NW_ITEMS + 255) / 256;
+  static_assert(NX_ITEMS <= 256, "one staging item per loader thread");
 };
 
 __device__ __forceinline__ unsigned pack_hi(float a, float b, float& ra, float& rb) {
@@ -54,206 +73,345 @@ __device__ __forceinline__ unsigned pack_lo(float a, float b) {
   return __builtin_bit_cast(unsigned, h);
 }
 
+// 16-byte slot of column `col` inside pixel `pix`'s 256-byte row of the X image.  The permutation makes the eight
+// lanes of a ds_write_b128 lane group (4 column quads of two neighbouring pixels, same column-in-quad) cover eight
+// distinct 16-byte residues mod 128 B (conflict-free; the natural order is 4-way conflicted), while a 16-lane read
+// group still reads a permutation of one 256-byte row (conflict-free ds_read_b128).
+__device__ __forceinline__ int xslot(int col, int pix) { return (((col & 3) << 2) + (col >> 2) + ((pix & 1) << 2)) & 15; }
+
+// PERSISTENT, role-specialised kernel: one workgroup of 8 waves per CU streams through its share of the work items
+// (item = pixel tile x 16-column slice x co group x sample).  Measured on the way here: with every wave alternating
+// staging and MFMA the two phases hardly overlap (MFMA pipe 37 % busy); with one non-persistent 112 KiB workgroup
+// per CU the dispatch gap, the first-load latency and the store tail of EVERY tile are exposed.
+//   waves 0..3  MFMA waves: LDS fragment reads (software-pipelined ring) + v_mfma only.  wave = 2*row + cohalf owns
+//               one tile row (PW = 2*PXW pixels) x CW = COT/2 output-channel tiles = 112 accumulator VGPRs.
+//   waves 4..7  loader waves: global -> registers (three register sets: two chunks of memory-latency slack) ->
+//               activation-derivative factor, hi/lo split -> LDS stage.  Their chunk stream runs across item
+//               boundaries, so only the first chunk of the launch sees memory latency.
+// Two LDS stages (2 x 56 KiB), ONE barrier per 8-channel chunk; both roles execute the same number of barriers.
 template <int COT, int PXW>
-__global__ __launch_bounds__(256, 2) void conv_tangent_bf16x3_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
-                                                                       int nslices, int ncog) {
+__global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
+                                                                       int nslices, int ncog, int total) {
   using C = BCfg<COT, PXW>;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C::XS_BYTES + 2 * C::WS_BYTES];
-  unsigned char* Xh = smem;
-  unsigned char* Xl = smem + C::XS_BYTES;
-  unsigned char* Wh = smem + 2 * C::XS_BYTES;
-  unsigned char* Wl = Wh + C::WS_BYTES;
+  constexpr int CW = COT / 2, PW = 2 * PXW;
+  static_assert(COT % 2 == 0, "the co-split wave layout needs an even number of output-channel tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages x [Xh | Xl | Wh | Wl]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
   const int kq = lane >> 4, cl = lane & 15;
+  const int nchunks = a.cin / 8;
 
-  int tile, slice, cog, np;
-  {  // XCD-aware work mapping, identical to conv_tangent.hip
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  // XCD-aware item list.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each): XCD k owns the
+  // contiguous logical range [xstart, xstart + xlen), ordered slice-fastest, then tile, then co group, then sample,
+  // and its workgroups take items j, j + nbx, j + 2 nbx ... so that what runs concurrently on an XCD shares 128-byte
+  // lines (column slices) and halos (neighbouring tiles) in its L2.  Speed only, never correctness.
+  int xstart, xlen, nbx, jx;
+  {
+    const int G = gridDim.x, bid = blockIdx.x, xcd = bid & 7;
+    const int q = total >> 3, r = total & 7;
+    xstart = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    xlen = q + (xcd < r ? 1 : 0);
+    nbx = (G - xcd + 7) >> 3;
+    jx = bid >> 3;
+  }
+  const int n_items = jx < xlen ? (xlen - jx + nbx - 1) / nbx : 0;
+  const int total_chunks = n_items * nchunks;
+  auto decode = [&](int item, int& tile, int& slice, int& cog, int& np) {
+    int w = xstart + jx + item * nbx;
     slice = w % nslices;
     w /= nslices;
     tile = w % ntiles;
     w /= ntiles;
     cog = w % ncog;
     np = w / ncog;
-  }
-  const int y0 = 2 * (tile / tiles_x), x0 = C::TW * (tile % tiles_x);
-  const int nchunks = a.cin / 8;
-  const int x_ci = (int)a.x_ci, x_px = (int)a.x_px, f_ci = (int)a.f_ci, f_px = (int)a.f_px;
-  const float* xb = a.x + (long long)np * a.x_np + slice * 16;
-  const float* fb = a.f ? a.f + (long long)np * a.f_np : a.x;    // never dereferenced when fmode == NONE
-  const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w) + (long long)cog * nchunks * C::W_CHUNK_BYTES;
-
-  // ---- staging plan: item = (pixel, column quad); loads are unconditional (clamped) ----
-  int xo[C::NXIT], fo[C::NXIT];
-  bool okv[C::NXIT];
-#pragma unroll
-  for (int it = 0; it < C::NXIT; ++it) {
-    const int i = tid + 256 * it;
-    const int q = i & 3, pix = i >> 2;
-    const int hy = pix / C::TWH, hx = pix % C::TWH;
-    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-    const bool ok = i < C::NX_ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const int gpix = gy * a.W + gx;
-    okv[it] = ok;
-    xo[it] = ok ? gpix * x_px + q * 4 : 0;
-    fo[it] = ok ? gpix * f_px : 0;
-  }
-  const float fzero = (a.fmode == CMF_F_TANH) ? 1.f : 0.f;
-
-  f32x4 xr[C::NXIT][8];
-  float fr[C::NXIT][8];
-  u32x4 wr[C::NWIT];
-
-  auto prefetch = [&](int ch) {
-#pragma unroll
-    for (int it = 0; it < C::NXIT; ++it)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ci = ch * 8 + j;
-        xr[it][j] = *reinterpret_cast<const f32x4*>(xb + ci * x_ci + xo[it]);
-        if (a.fmode != CMF_F_NONE) {
-          const float fv = fb[ci * f_ci + fo[it]];
-          fr[it][j] = okv[it] ? fv : fzero;
-        } else {
-          fr[it][j] = okv[it] ? 1.f : 0.f;
-        }
-      }
-#pragma unroll
-    for (int it = 0; it < C::NWIT; ++it) {
-      int i = tid + 256 * it;
-      i = i < C::NW_ITEMS ? i : C::NW_ITEMS - 1;
-      // item -> (hl, s, cot, rest 64): the global slab always has 4 co tiles per K-step
-      const int rest = i & 63, t = i >> 6;
-      const int cot = t % COT, s = (t / COT) % 3, hl = t / (3 * COT);
-      wr[it] = *reinterpret_cast<const u32x4*>(wb + (long long)ch * C::W_CHUNK_BYTES +
-                                               ((((hl * 3 + s) * 4 + cot) * 64 + rest) << 4));
-    }
   };
 
-  auto commit = [&]() {
+  if (loader) {
+    // =============================== loader waves ===============================
+    // Measured with in-kernel stamps: a loader's ~220 VALU + 14 ds_write per chunk took ~4000 cycles beside an MFMA
+    // wave on the same SIMD and set the chunk period.  VALU issue is arbitrated by priority, then age: raise the
+    // loaders (an MFMA wave needs one issue slot per 16 cycles and barely notices).
+    __builtin_amdgcn_s_setprio(3);
+    const int lt = tid - 256;                                    // 0..255: staging item = (pixel, column quad)
+    const int x_ci = (int)a.x_ci, x_px = (int)a.x_px, f_ci = (int)a.f_ci, f_px = (int)a.f_px;
+    const int q = lt & 3, pix = lt >> 2;
+    const int hy = pix / C::TWH, hx = pix % C::TWH;
+    // NONE: 1   RELU: [f>0]   TANH: 1 - f^2   RAW: f      as  okf * (c0 + c1*[f>0] + c2*f + c3*f*f)
+    const float fc0 = (a.fmode == CMF_F_NONE || a.fmode == CMF_F_TANH) ? 1.f : 0.f;
+    const float fc1 = (a.fmode == CMF_F_RELU) ? 1.f : 0.f;
+    const float fc2 = (a.fmode == CMF_F_RAW) ? 1.f : 0.f;
+    const float fc3 = (a.fmode == CMF_F_TANH) ? -1.f : 0.f;
+
+    // prefetch cursor: which (work item, chunk) the next prefetch fetches, with that item's addressing state.
+    // Bases are wave-uniform; per-lane offsets are unsigned 32-bit BYTE offsets (SGPR-base loads, no 64-bit per-lane
+    // addresses kept alive).  Validity is applied arithmetically at commit time: every load is unconditional and
+    // always consumed (a select on validity lets hipcc sink loads into branches + s_waitcnt vmcnt(0)).
+    int cur_item = 0, cur_ch = 0;
+    const float* xb = a.x;
+    const float* fb = a.x;
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w);
+    unsigned xo = 0, fo = 0;
+    float okf = 0.f;
+    auto set_item = [&](int item) {
+      int tile, slice, cog, np;
+      decode(item, tile, slice, cog, np);
+      const int y0 = 2 * (tile / tiles_x), x0 = C::TW * (tile % tiles_x);
+      xb = a.x + (long long)np * a.x_np + slice * 16;
+      fb = a.f ? a.f + (long long)np * a.f_np : a.x;
+      wb = reinterpret_cast<const unsigned char*>(a.w) + (long long)cog * nchunks * C::W_CHUNK_BYTES;
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      const bool ok = lt < C::NX_ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const int gpix = gy * a.W + gx;
+      okf = ok ? 1.f : 0.f;
+      xo = ok ? 4u * (unsigned)(gpix * x_px + q * 4) : 0u;
+      fo = ok ? 4u * (unsigned)(gpix * f_px) : 0u;
+    };
+
+    struct Regs {
+      f32x4 x[8];
+      float f[8];
+      u32x4 w[C::NWIT];
+      float okf;
+    };
+    Regs r0, r1, r2;                                               // chunk g of the stream lives in set g % 3
 #pragma unroll
-    for (int it = 0; it < C::NXIT; ++it) {
-      const int i = tid + 256 * it;
-      if (i < C::NX_ITEMS) {
+    for (int j = 0; j < 8; ++j) r0.f[j] = r1.f[j] = r2.f[j] = 0.f;  // stays 0 when fmode == NONE (never loaded)
+
+    auto prefetch = [&](Regs& r) {
+      const int ch = cur_ch;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned off = 4u * (unsigned)((ch * 8 + j) * x_ci) + xo;
+#ifndef CMF_DBG_NOLOAD
+        r.x[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(xb) + off);
+#else
+        r.x[j] = f32x4{(float)off, 1.f, 2.f, 3.f};
+#endif
+      }
+      if (a.fmode != CMF_F_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned off = 4u * (unsigned)((ch * 8 + j) * f_ci) + fo;
+          r.f[j] = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(fb) + off);
+        }
+      }
+      const unsigned wco = (unsigned)(ch * C::W_CHUNK_BYTES);
+#pragma unroll
+      for (int it = 0; it < C::NWIT; ++it) {
+        int i = lt + 256 * it;
+        i = i < C::NW_ITEMS ? i : C::NW_ITEMS - 1;
+        unsigned off;
+        if (COT == 4) {
+          off = (unsigned)i << 4;                                  // the slab is consumed whole: a linear copy
+        } else {                                                   // the global slab always has 4 co tiles per K-step
+          const int rest = i & 63, t = i >> 6;
+          const int cot = t % COT, s = (t / COT) % 3, hl = t / (3 * COT);
+          off = (unsigned)((((hl * 3 + s) * 4 + cot) * 64 + rest) << 4);
+        }
+        r.w[it] = *reinterpret_cast<const u32x4*>(wb + (wco + off));
+      }
+      r.okf = okf;
+      if (++cur_ch == nchunks) {                                   // advance the cursor (wave-uniform)
+        cur_ch = 0;
+        if (++cur_item < n_items) set_item(cur_item);
+      }
+    };
+
+    auto commit = [&](Regs& r, int stage) {
+#ifdef CMF_DBG_NOCOMMIT
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(r.x[j]), "v"(r.f[j]));
+#pragma unroll
+      for (int it = 0; it < C::NWIT; ++it) asm volatile("" ::"v"(r.w[it]));
+      return;
+#endif
+      unsigned char* Xh = smem + stage * C::BUF_BYTES;
+      unsigned char* Xl = Xh + C::XS_BYTES;
+      unsigned char* Wh = Xh + 2 * C::XS_BYTES;
+      unsigned char* Wl = Wh + C::WS_BYTES;
+      if (lt < C::NX_ITEMS) {
         float v[8][4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float m = fr[it][j];
-          if (a.fmode == CMF_F_RELU) m = m > 0.f ? 1.f : 0.f;
-          else if (a.fmode == CMF_F_TANH) m = 1.f - m * m;
+          const float f = r.f[j];
+          const float m = r.okf * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[j][c] = xr[it][j][c] * m;
+          for (int c = 0; c < 4; ++c) v[j][c] = r.x[j][c] * m;
         }
-        const int q = i & 3, pix = i >> 2;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {           // column q*4 + c: 8 channels -> 16 B hi + 16 B lo
+        for (int c = 0; c < 4; ++c) {                              // column q*4 + c: 8 channels -> 16 B hi + 16 B lo
           u32x4 h, l;
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
-            float ra, rb;
-            h[jj] = pack_hi(v[2 * jj][c], v[2 * jj + 1][c], ra, rb);
-            l[jj] = pack_lo(ra, rb);
+            float e0, e1;
+            h[jj] = pack_hi(v[2 * jj][c], v[2 * jj + 1][c], e0, e1);
+            l[jj] = pack_lo(e0, e1);
           }
-          const int off = ((pix * 16 + q * 4 + c) << 4);
+          const int off = ((pix * 16 + xslot(q * 4 + c, pix)) << 4);
           *reinterpret_cast<u32x4*>(Xh + off) = h;
           *reinterpret_cast<u32x4*>(Xl + off) = l;
         }
       }
-    }
 #pragma unroll
-    for (int it = 0; it < C::NWIT; ++it) {
-      const int i = tid + 256 * it;
-      if (i < C::NW_ITEMS) {
-        const int rest = i & 63, t = i >> 6;
-        const int cot = t % COT, s = (t / COT) % 3, hl = t / (3 * COT);
-        unsigned char* dst = (hl ? Wl : Wh) + ((((s * COT + cot) * 64) + rest) << 4);
-        *reinterpret_cast<u32x4*>(dst) = wr[it];
+      for (int it = 0; it < C::NWIT; ++it) {
+        const int i = lt + 256 * it;
+        if (i < C::NW_ITEMS) {
+          const int rest = i & 63, t = i >> 6;
+          const int cot = t % COT, s = (t / COT) % 3, hl = t / (3 * COT);
+          unsigned char* dst = (hl ? Wl : Wh) + ((((s * COT + cot) * 64) + rest) << 4);
+          *reinterpret_cast<u32x4*>(dst) = r.w[it];
+        }
       }
+    };
+
+    if (n_items > 0) set_item(0);
+    if (total_chunks > 0) prefetch(r0);
+    if (total_chunks > 1) prefetch(r1);
+    if (total_chunks > 2) prefetch(r2);
+    if (total_chunks > 0) commit(r0, 0);
+    __syncthreads();                                               // stage 0 ready
+    // iteration g: the MFMA waves consume stage g&1 (stream chunk g); set g%3 is free -> stream chunk g+3;
+    // stage (g+1)&1 <- chunk g+1 from set (g+1)%3.  Exactly one barrier per iteration, matching the MFMA waves.
+    auto iter = [&](int g, Regs& freed, Regs& next) {
+      STAMP(1, g, 0);
+      if (g + 3 < total_chunks) prefetch(freed);
+      STAMP(1, g, 1);
+#ifdef CMF_DBG_STAMP
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 8 + C::NWIT));   // the loads of `next` have landed (this set's may fly)
+      STAMP(1, g, 2);
+#endif
+      if (g + 1 < total_chunks) commit(next, (g + 1) & 1);
+      STAMP(1, g, 3);
+      __syncthreads();
+    };
+    for (int g = 0; g < total_chunks; g += 3) {
+      iter(g, r0, r1);
+      if (g + 1 >= total_chunks) break;
+      iter(g + 1, r1, r2);
+      if (g + 2 >= total_chunks) break;
+      iter(g + 2, r2, r0);
     }
-  };
+    return;
+  }
 
-  f32x4 acc[PXW][COT];
-#pragma unroll
-  for (int p = 0; p < PXW; ++p)
-#pragma unroll
-    for (int c = 0; c < COT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ================================= MFMA waves =================================
+  const int wrow = wave >> 1, cohalf = wave & 1;
+  const int y_co = (int)a.y_co, y_px = (int)a.y_px, r_co = (int)a.r_co, r_px = (int)a.r_px;
 
-  // per-lane B offsets of the three K-steps: lane group kq of step s reads tap 4*s + kq (taps >= 9 read tap 8's
-  // data against zero weights)
-  const int wrow = wave >> 1, wx = (wave & 1) * PXW;
-  int boff[3];
+  // Per-lane B offsets: lane group kq of K-step s reads tap 4*s + kq (taps >= 9 read tap 8's data against zero
+  // weights) of pixel (wrow + dy, p + dx); the slot permutation depends on the pixel's parity, i.e. on (dx + p) & 1
+  // (the halo row length TWH is even).
+  int boff[3][2];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     int tap = 4 * s + kq;
     tap = tap < 9 ? tap : 8;
-    boff[s] = ((((wrow + tap / 3) * C::TWH + wx + tap % 3) * 16 + cl) << 4);
+    const int pbase = (wrow + tap / 3) * C::TWH + tap % 3;         // staged pixel of p = 0
+#pragma unroll
+    for (int par = 0; par < 2; ++par) boff[s][par] = ((pbase * 16 + xslot(cl, pbase + par)) << 4);
   }
-  const int aoff = lane << 4;
+  const int aoff = (lane << 4) + ((cohalf * CW * 64) << 4);
 
-  prefetch(0);
-  for (int ch = 0; ch < nchunks; ++ch) {
-    commit();
-    __syncthreads();
-    if (ch + 1 < nchunks) prefetch(ch + 1);
+  // Fragment pipeline: step t = s*PW + p consumes B fragment pair t; pairs are fetched BD-1 steps ahead into a ring
+  // of BD register pairs, the A fragments of K-step s+1 are fetched at the start of K-step s into the alternate
+  // set.  Everything is unrolled, so ring slots are static registers and hipcc emits counted lgkmcnt waits.
+  constexpr int BD = 4, NSTEP = 3 * PW;
+  int g = 0;                                                       // stream chunk index -> LDS stage g & 1
+  __syncthreads();                                                 // stage 0 ready
+  for (int item = 0; item < n_items; ++item) {
+    int tile, slice, cog, np;
+    decode(item, tile, slice, cog, np);
+    const int y0 = 2 * (tile / tiles_x), x0 = C::TW * (tile % tiles_x);
+    // lane (kq, cl) owns columns slice*16 + kq*4 .. +3 of output channel co0 + c*16
+    float* ybase = a.y + (long long)np * a.y_np + slice * 16 + kq * 4;
+    const float* rbase = a.r ? a.r + (long long)np * a.r_np + slice * 16 + kq * 4 : nullptr;
+    const int co0 = cog * 64 + cohalf * CW * 16 + cl;
+    const bool full = (cog * 64 + COT * 16) <= a.cout;
+
+    f32x4 acc[PW][CW];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      bf16x8 ah[COT], al[COT];
+    for (int p = 0; p < PW; ++p)
 #pragma unroll
-      for (int c = 0; c < COT; ++c) {
-        ah[c] = *reinterpret_cast<const bf16x8*>(Wh + (((s * COT + c) * 64) << 4) + aoff);
-        al[c] = *reinterpret_cast<const bf16x8*>(Wl + (((s * COT + c) * 64) << 4) + aoff);
-      }
+      for (int c = 0; c < CW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The residual is the accumulators' initial value: its 64-byte-segment loads sit in front of the item's first
+    // MFMAs (under the loaders' staging) rather than in the store tail.
+    if (rbase) {
 #pragma unroll
-      for (int p = 0; p < PXW; ++p) {
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Xh + boff[s] + p * 256);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Xl + boff[s] + p * 256);
+      for (int p = 0; p < PW; ++p) {
+        const int gy = y0 + wrow, gx = x0 + p;
+        if (!(gy < a.H && gx < a.W)) continue;
+        const float* rp = rbase + (gy * a.W + gx) * r_px + co0 * r_co;
 #pragma unroll
-        for (int c = 0; c < COT; ++c) {
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[c], bh, acc[p][c], 0, 0, 0);
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c], bl, acc[p][c], 0, 0, 0);
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c], bh, acc[p][c], 0, 0, 0);
-        }
+        for (int c = 0; c < CW; ++c)
+          if (full || (co0 + c * 16) < a.cout) acc[p][c] = *reinterpret_cast<const f32x4*>(rp + (c * 16) * r_co);
       }
     }
-    __syncthreads();
-  }
 
-  // ---- epilogue (as conv_tangent.hip) ----
-  const int y_co = (int)a.y_co, y_px = (int)a.y_px, r_co = (int)a.r_co, r_px = (int)a.r_px;
-  float* ybase = a.y + (long long)np * a.y_np + slice * 16 + cl;
-  const float* rbase = a.r ? a.r + (long long)np * a.r_np + slice * 16 + cl : nullptr;
-  const int co0 = cog * 64 + kq * 4;
-  const bool full = (cog * 64 + COT * 16) <= a.cout;
-  auto store_all = [&](auto has_res, auto is_full) {
+    for (int ch = 0; ch < nchunks; ++ch, ++g) {
+      const unsigned char* Xh = smem + (g & 1) * C::BUF_BYTES;
+      const unsigned char* Xl = Xh + C::XS_BYTES;
+      const unsigned char* Wh = Xh + 2 * C::XS_BYTES;
+      const unsigned char* Wl = Wh + C::WS_BYTES;
+      bf16x8 ah[2][CW], al[2][CW], bh[BD], bl[BD];
+      auto load_a = [&](int s, int set) {
 #pragma unroll
-    for (int p = 0; p < PXW; ++p) {
-      const int gy = y0 + wrow, gx = x0 + wx + p;
-      if (!(gy < a.H && gx < a.W)) continue;
-      const int gpix = gy * a.W + gx;
-      float* yp = ybase + gpix * y_px + co0 * y_co;
-      const float* rp = has_res ? rbase + gpix * r_px + co0 * r_co : nullptr;
-#pragma unroll
-      for (int c = 0; c < COT; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (is_full || (co0 + c * 16 + r) < a.cout) {
-            float v = acc[p][c][r];
-            if (has_res) v += rp[(c * 16 + r) * r_co];
-            yp[(c * 16 + r) * y_co] = v;
-          }
+        for (int c = 0; c < CW; ++c) {
+          ah[set][c] = *reinterpret_cast<const bf16x8*>(Wh + (((s * COT + c) * 64) << 4) + aoff);
+          al[set][c] = *reinterpret_cast<const bf16x8*>(Wl + (((s * COT + c) * 64) << 4) + aoff);
         }
+      };
+      auto load_b = [&](int t) {
+        const int s = t / PW, p = t % PW;
+        bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][p & 1] + p * 256);
+        bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][p & 1] + p * 256);
+      };
+      STAMP(0, g, 0);
+      load_a(0, 0);
+#pragma unroll
+      for (int t = 0; t < BD - 1; ++t) load_b(t);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NSTEP; ++t) {
+        const int s = t / PW, p = t % PW;
+        if (t + BD - 1 < NSTEP) load_b(t + BD - 1);
+        if (p == 0 && s + 1 < 3) load_a(s + 1, (s + 1) & 1);
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+#ifndef CMF_DBG_NOMFMA
+          // D[row = Jacobian column][col = output channel] = X-fragment (as A) x W-fragment (as B): each lane then
+          // holds 4 CONSECUTIVE columns (rows kq*4 + r) of channel cl -> 16-byte stores / residual loads
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], al[s & 1][c], acc[p][c], 0, 0, 0);
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s & 1][c], acc[p][c], 0, 0, 0);
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s & 1][c], acc[p][c], 0, 0, 0);
+#else       // timing-only builds (tools/bench_conv.py --lib): keep the operands live, skip the matrix pipe
+          asm volatile("" ::"v"(al[s & 1][c]), "v"(ah[s & 1][c]), "v"(bh[t % BD]), "v"(bl[t % BD]));
+#endif
+        }
+        // keep this step's reads-then-MFMAs order: without the fence hipcc's scheduler re-clusters the ds_reads next
+        // to their uses (lgkmcnt(0) before most MFMA groups) and the ring no longer hides LDS latency
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      STAMP(0, g, 1);
+      __syncthreads();                                             // stage (g+1)&1 ready, stage g&1 free
+      STAMP(0, g, 2);
     }
-  };
-  if (rbase) {
-    if (full) store_all(std::true_type{}, std::true_type{});
-    else store_all(std::true_type{}, std::false_type{});
-  } else {
-    if (full) store_all(std::false_type{}, std::true_type{});
-    else store_all(std::false_type{}, std::false_type{});
+
+    // ---- store tail of this item ----
+    auto store_all = [&](auto is_full) {
+#pragma unroll
+      for (int p = 0; p < PW; ++p) {
+        const int gy = y0 + wrow, gx = x0 + p;
+        if (!(gy < a.H && gx < a.W)) continue;
+        float* yp = ybase + (gy * a.W + gx) * y_px + co0 * y_co;
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+          if (is_full || (co0 + c * 16) < a.cout) *reinterpret_cast<f32x4*>(yp + (c * 16) * y_co) = acc[p][c];
+      }
+    };
+    if (full) store_all(std::true_type{});
+    else store_all(std::false_type{});
   }
 }
 
@@ -281,28 +439,34 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned 
 
 template <int COT, int PXW>
 int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
+  using C = BCfg<COT, PXW>;
   const int tiles_x = cmf_ceil_div(a.W, 2 * PXW), tiles = tiles_x * cmf_ceil_div(a.H, 2);
   const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
-  hipLaunchKernelGGL((conv_tangent_bf16x3_kernel<COT, PXW>), dim3((unsigned)total), dim3(256), 0, s, a, tiles_x, tiles,
-                     nslices, ncog);
+  auto k = conv_tangent_bf16x3_kernel<COT, PXW>;
+  constexpr int lds = 2 * C::BUF_BYTES;
+  static int n_cu = 0;                          // idempotent initialisation; a benign race at worst repeats it
+  if (n_cu == 0) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+    n_cu = cus > 0 ? cus : 256;
+  }
+  const int grid = (int)(total < n_cu ? total : n_cu);          // persistent: one 112 KiB workgroup per CU
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles, nslices, ncog, (int)total);
   CMF_LAUNCH_CHECK();
   return 0;
 }
 
 template <int PXW>
 int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
-  const int cot = (a.cout >= 64) ? 4 : (a.cout + 15) / 16;
-  switch (cot) {
-    case 1: return launch<1, PXW>(a, s);
-    case 2: return launch<2, PXW>(a, s);
-    case 3: return launch<3, PXW>(a, s);
-    default: return launch<4, PXW>(a, s);
-  }
+  return (a.cout > 32) ? launch<4, PXW>(a, s) : launch<2, PXW>(a, s);   // co tiles per workgroup: 64 or 32 channels
 }
 
-inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 31); }
+inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 29); }   // element offsets; x4 bytes must fit 32 bits
 
 }  // namespace
 
@@ -325,6 +489,8 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   if (a.taps != 9 || a.cin % 8 || a.nc <= 0 || a.nc % 16) return CMF_EINVAL;
   if (a.fmode < CMF_F_NONE || a.fmode > CMF_F_RAW || (a.fmode != CMF_F_NONE && !a.f)) return CMF_EINVAL;
   if ((a.x_np | a.x_ci | a.x_px) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
+  if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;            // 16-byte stores
+  if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;    // 16-byte residual loads
   const long long HW = (long long)a.H * a.W;
   if (!fits_int((a.cin + 8) * a.x_ci + HW * a.x_px + a.nc) || !fits_int((a.cin + 8) * a.f_ci + HW * a.f_px) ||
       !fits_int((a.cout + 64) * a.y_co + HW * a.y_px + a.nc) || (a.r && !fits_int((a.cout + 64) * a.r_co + HW * a.r_px + a.nc)) ||

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the tangent-conv kernels through the C ABI (optionally against debug builds of the library).
+
+  python tools/bench_conv.py [--lib path.so] [--B 128] [--hw 28] [--res 0|1] [--precision bf16x3|f32]
+"""
+import argparse, ctypes as C, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default=None); ap.add_argument("--B", type=int, default=128); ap.add_argument("--hw", type=int, default=28)
+ap.add_argument("--res", type=int, default=1); ap.add_argument("--precision", default="bf16x3"); ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--fmode", default="relu")
+args = ap.parse_args()
+from cmf_amd import _lib
+if args.lib:
+    _lib.LIB_PATH = os.path.abspath(args.lib)
+from cmf_amd import engine as E
+E.TANGENT_PRECISION = args.precision
+B, H, nc, ch = args.B, args.hw, 64, 64
+HW = H * H
+x = torch.randn(B, ch, H, H, nc, device="cuda"); prim = torch.randn(B, ch, H, H, device="cuda")
+res = torch.randn(B, ch, H, H, nc, device="cuda") if args.res else None
+y = torch.empty(B, ch, H, H, nc, device="cuda")
+w = torch.nn.Parameter(torch.randn(ch, ch, 3, 3, device="cuda") / 24)
+fm = {"relu": E.F_RELU, "none": E.F_NONE}[args.fmode]
+def run():
+    E.conv_tangent(x, 0, ch * HW * nc, HW * nc, nc, w, 9, y, ch * HW * nc, HW * nc, nc, B, ch, ch, H, H, nc, fmode=fm,
+                   f=prim if fm else None, f_np=ch * HW, f_ci=HW, f_px=1, res_t=res)
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(args.iters): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / args.iters
+fl = 2.0 * ch * ch * 9 * HW * nc * B
+print(f"{os.path.basename(args.lib or 'libcmf_amd.so'):28s} B={B} {H}x{H} res={args.res} {args.precision}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s  "
+      f"{4.0*HW*nc*B*ch*(2+args.res)/ms/1e6:7.1f} GB/s")
