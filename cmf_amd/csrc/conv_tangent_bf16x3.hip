@@ -24,13 +24,13 @@
 
 #ifdef CMF_DBG_STAMP
 // diagnostic build only: phase timestamps of workgroup 0 (wave 0 = MFMA role, wave 4 = loader role)
-__device__ unsigned long long cmf_dbg_stamps[2][64][4];
+__device__ unsigned long long cmf_dbg_stamps[3][64][4];
 extern "C" int cmf_debug_read_stamps(void* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cmf_dbg_stamps), sizeof(cmf_dbg_stamps));
 }
 #define STAMP(role, g, k)                                                                        \
   do {                                                                                            \
-    if (blockIdx.x == 0 && (g) < 64 && lane == 0 && wave == ((role) ? 4 : 0)) {                   \
+    if (blockIdx.x == 0 && (g) < 64 && lane == 0 && wave == ((role) == 1 ? 4 : 0)) {                   \
       unsigned long long t_;                                                                      \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
       cmf_dbg_stamps[role][g][k] = t_;                                                            \
@@ -318,100 +318,116 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // of BD register pairs, the A fragments of K-step s+1 are fetched at the start of K-step s into the alternate
   // set.  Everything is unrolled, so ring slots are static registers and hipcc emits counted lgkmcnt waits.
   constexpr int BD = 4, NSTEP = 3 * PW;
-  int g = 0;                                                       // stream chunk index -> LDS stage g & 1
-  __syncthreads();                                                 // stage 0 ready
-  for (int item = 0; item < n_items; ++item) {
+
+  // Item context: output / residual bases and validity of this wave's tile row.
+  struct Item {
+    float* y;
+    const float* r;
+    int y0, x0, co0;
+    bool full;
+  };
+  auto make_item = [&](int item) {
     int tile, slice, cog, np;
     decode(item, tile, slice, cog, np);
-    const int y0 = 2 * (tile / tiles_x), x0 = C::TW * (tile % tiles_x);
+    Item it;
+    it.y0 = 2 * (tile / tiles_x);
+    it.x0 = C::TW * (tile % tiles_x);
     // lane (kq, cl) owns columns slice*16 + kq*4 .. +3 of output channel co0 + c*16
-    float* ybase = a.y + (long long)np * a.y_np + slice * 16 + kq * 4;
-    const float* rbase = a.r ? a.r + (long long)np * a.r_np + slice * 16 + kq * 4 : nullptr;
-    const int co0 = cog * 64 + cohalf * CW * 16 + cl;
-    const bool full = (cog * 64 + COT * 16) <= a.cout;
-
-    f32x4 acc[PW][CW];
+    it.y = a.y + (long long)np * a.y_np + slice * 16 + kq * 4;
+    it.r = a.r ? a.r + (long long)np * a.r_np + slice * 16 + kq * 4 : nullptr;
+    it.co0 = cog * 64 + cohalf * CW * 16 + cl;
+    it.full = (cog * 64 + COT * 16) <= a.cout;
+    return it;
+  };
+  f32x4 acc[PW][CW];
+  // accumulator initial value of pixel p = residual (or zero)
+  auto init_pixel = [&](const Item& it, int p) {
+    const int gy = it.y0 + wrow, gx = it.x0 + p;
 #pragma unroll
-    for (int p = 0; p < PW; ++p)
+    for (int c = 0; c < CW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (it.r && gy < a.H && gx < a.W) {
+      const float* rp = it.r + (gy * a.W + gx) * r_px + it.co0 * r_co;
 #pragma unroll
-      for (int c = 0; c < CW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // The residual is the accumulators' initial value: its 64-byte-segment loads sit in front of the item's first
-    // MFMAs (under the loaders' staging) rather than in the store tail.
-    if (rbase) {
-#pragma unroll
-      for (int p = 0; p < PW; ++p) {
-        const int gy = y0 + wrow, gx = x0 + p;
-        if (!(gy < a.H && gx < a.W)) continue;
-        const float* rp = rbase + (gy * a.W + gx) * r_px + co0 * r_co;
-#pragma unroll
-        for (int c = 0; c < CW; ++c)
-          if (full || (co0 + c * 16) < a.cout) acc[p][c] = *reinterpret_cast<const f32x4*>(rp + (c * 16) * r_co);
-      }
+      for (int c = 0; c < CW; ++c)
+        if (it.full || (it.co0 + c * 16) < a.cout) acc[p][c] = *reinterpret_cast<const f32x4*>(rp + (c * 16) * r_co);
     }
+  };
+  auto store_pixel = [&](const Item& it, int p) {
+    const int gy = it.y0 + wrow, gx = it.x0 + p;
+    if (!(gy < a.H && gx < a.W)) return;
+    float* yp = it.y + (gy * a.W + gx) * y_px + it.co0 * y_co;
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
+      if (it.full || (it.co0 + c * 16) < a.cout) *reinterpret_cast<f32x4*>(yp + (c * 16) * y_co) = acc[p][c];
+  };
 
-    for (int ch = 0; ch < nchunks; ++ch, ++g) {
-      const unsigned char* Xh = smem + (g & 1) * C::BUF_BYTES;
-      const unsigned char* Xl = Xh + C::XS_BYTES;
-      const unsigned char* Wh = Xh + 2 * C::XS_BYTES;
-      const unsigned char* Wl = Wh + C::WS_BYTES;
-      bf16x8 ah[2][CW], al[2][CW], bh[BD], bl[BD];
-      auto load_a = [&](int s, int set) {
+  // One 8-channel chunk from LDS stage `stage`.  LAST = the item's final chunk: pixel p's accumulators are final
+  // after its K-step-2 MFMAs, so its 16-byte stores are issued right there and the NEXT item's residual loads go
+  // straight into the freed registers -- the VMEM issue cost of the tail (measured ~335 cycles per store / load
+  // instruction, ~9.4k + ~9k cycles per item when done as a block) hides under the remaining MFMAs.
+  auto chunk = [&](int stage, auto LAST, const Item& cur, const Item& nxt, bool has_next) {
+    const unsigned char* Xh = smem + stage * C::BUF_BYTES;
+    const unsigned char* Xl = Xh + C::XS_BYTES;
+    const unsigned char* Wh = Xh + 2 * C::XS_BYTES;
+    const unsigned char* Wl = Wh + C::WS_BYTES;
+    bf16x8 ah[2][CW], al[2][CW], bh[BD], bl[BD];
+    auto load_a = [&](int s, int set) {
 #pragma unroll
-        for (int c = 0; c < CW; ++c) {
-          ah[set][c] = *reinterpret_cast<const bf16x8*>(Wh + (((s * COT + c) * 64) << 4) + aoff);
-          al[set][c] = *reinterpret_cast<const bf16x8*>(Wl + (((s * COT + c) * 64) << 4) + aoff);
-        }
-      };
-      auto load_b = [&](int t) {
-        const int s = t / PW, p = t % PW;
-        bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][p & 1] + p * 256);
-        bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][p & 1] + p * 256);
-      };
-      STAMP(0, g, 0);
-      load_a(0, 0);
-#pragma unroll
-      for (int t = 0; t < BD - 1; ++t) load_b(t);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < NSTEP; ++t) {
-        const int s = t / PW, p = t % PW;
-        if (t + BD - 1 < NSTEP) load_b(t + BD - 1);
-        if (p == 0 && s + 1 < 3) load_a(s + 1, (s + 1) & 1);
-#pragma unroll
-        for (int c = 0; c < CW; ++c) {
-#ifndef CMF_DBG_NOMFMA
-          // D[row = Jacobian column][col = output channel] = X-fragment (as A) x W-fragment (as B): each lane then
-          // holds 4 CONSECUTIVE columns (rows kq*4 + r) of channel cl -> 16-byte stores / residual loads
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], al[s & 1][c], acc[p][c], 0, 0, 0);
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s & 1][c], acc[p][c], 0, 0, 0);
-          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s & 1][c], acc[p][c], 0, 0, 0);
-#else       // timing-only builds (tools/bench_conv.py --lib): keep the operands live, skip the matrix pipe
-          asm volatile("" ::"v"(al[s & 1][c]), "v"(ah[s & 1][c]), "v"(bh[t % BD]), "v"(bl[t % BD]));
-#endif
-        }
-        // keep this step's reads-then-MFMAs order: without the fence hipcc's scheduler re-clusters the ds_reads next
-        // to their uses (lgkmcnt(0) before most MFMA groups) and the ring no longer hides LDS latency
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      STAMP(0, g, 1);
-      __syncthreads();                                             // stage (g+1)&1 ready, stage g&1 free
-      STAMP(0, g, 2);
-    }
-
-    // ---- store tail of this item ----
-    auto store_all = [&](auto is_full) {
-#pragma unroll
-      for (int p = 0; p < PW; ++p) {
-        const int gy = y0 + wrow, gx = x0 + p;
-        if (!(gy < a.H && gx < a.W)) continue;
-        float* yp = ybase + (gy * a.W + gx) * y_px + co0 * y_co;
-#pragma unroll
-        for (int c = 0; c < CW; ++c)
-          if (is_full || (co0 + c * 16) < a.cout) *reinterpret_cast<f32x4*>(yp + (c * 16) * y_co) = acc[p][c];
+      for (int c = 0; c < CW; ++c) {
+        ah[set][c] = *reinterpret_cast<const bf16x8*>(Wh + (((s * COT + c) * 64) << 4) + aoff);
+        al[set][c] = *reinterpret_cast<const bf16x8*>(Wl + (((s * COT + c) * 64) << 4) + aoff);
       }
     };
-    if (full) store_all(std::true_type{});
-    else store_all(std::false_type{});
+    auto load_b = [&](int t) {
+      const int s = t / PW, p = t % PW;
+      bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][p & 1] + p * 256);
+      bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][p & 1] + p * 256);
+    };
+    load_a(0, 0);
+#pragma unroll
+    for (int t = 0; t < BD - 1; ++t) load_b(t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t) {
+      const int s = t / PW, p = t % PW;
+      if (t + BD - 1 < NSTEP) load_b(t + BD - 1);
+      if (p == 0 && s + 1 < 3) load_a(s + 1, (s + 1) & 1);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        // D[row = Jacobian column][col = output channel] = X-fragment (as A) x W-fragment (as B): each lane then
+        // holds 4 CONSECUTIVE columns (rows kq*4 + r) of channel cl -> 16-byte stores / residual loads
+        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], al[s & 1][c], acc[p][c], 0, 0, 0);
+        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s & 1][c], acc[p][c], 0, 0, 0);
+        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s & 1][c], acc[p][c], 0, 0, 0);
+      }
+      if (LAST && s == 2) {
+        store_pixel(cur, p);
+        if (has_next) init_pixel(nxt, p);
+      }
+      // keep this step's reads-then-MFMAs(-then-tail) order: without the fence hipcc's scheduler re-clusters the
+      // ds_reads next to their uses (lgkmcnt(0) before most MFMA groups) and the ring no longer hides LDS latency
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  int g = 0;                                                       // stream chunk index -> LDS stage g & 1
+  Item cur = make_item(0), nxt = cur;
+  if (n_items > 0) {
+#pragma unroll
+    for (int p = 0; p < PW; ++p) init_pixel(cur, p);
+  }
+  __syncthreads();                                                 // stage 0 ready
+  for (int item = 0; item < n_items; ++item) {
+    const bool has_next = item + 1 < n_items;
+    if (has_next) nxt = make_item(item + 1);
+    for (int ch = 0; ch < nchunks - 1; ++ch, ++g) {
+      chunk(g & 1, std::false_type{}, cur, nxt, has_next);
+      __syncthreads();                                             // stage (g+1)&1 ready, stage g&1 free
+    }
+    chunk(g & 1, std::true_type{}, cur, nxt, has_next);
+    __syncthreads();
+    ++g;
+    cur = nxt;
   }
 }
 

@@ -15,7 +15,7 @@ def run():
     E.conv_tangent(x, 0, ch*HW*nc, HW*nc, nc, w, 9, y, ch*HW*nc, HW*nc, nc, B, ch, ch, H, H, nc, fmode=E.F_RELU, f=prim, f_np=ch*HW, f_ci=HW, f_px=1, res_t=r)
 for _ in range(3): run()
 torch.cuda.synchronize()
-buf = np.zeros((2, 64, 4), dtype=np.uint64)
+buf = np.zeros((3, 64, 4), dtype=np.uint64)
 lib = _lib.load(); lib.cmf_debug_read_stamps.argtypes = [C.c_void_p]
 assert lib.cmf_debug_read_stamps(buf.ctypes.data) == 0
 M, L = buf[0].astype(np.int64), buf[1].astype(np.int64)
@@ -26,3 +26,8 @@ for g in range(24):
 print("loader wave: g  start  prefetch_issue  wait_loads  commit  (then barrier)")
 for g in range(24):
     print(f"  g={g:2d} start={L[g,0]-t0:8d} issue={L[g,1]-L[g,0]:6d} wait={L[g,2]-L[g,1]:6d} commit={L[g,3]-L[g,2]:6d} next_start-gap={L[g+1,0]-L[g,3]:6d}")
+
+I = buf[2].astype(np.int64)
+print("item: decode_done->acc_init_issued, first chunk start - that, loop_end->stores_issued, next item decode gap")
+for it in range(4):
+    print(f"  item={it} t_decode={I[it,0]-t0:8d} init_issue={I[it,1]-I[it,0]:6d} first_mfma_chunk_start={M[it*8,0]-I[it,1]:6d} loop={I[it,2]-I[it,1]:7d} stores={I[it,3]-I[it,2]:6d} to_next_decode={I[it+1,0]-I[it,3]:6d}")
