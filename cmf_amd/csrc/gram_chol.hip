@@ -193,6 +193,10 @@ __global__ __launch_bounds__(256) void chol_retry_kernel(float* __restrict__ jtj
   report(b, inf, ld, logdet, info, fail + attempt);
 }
 
+__global__ void zero_flags_kernel(int* __restrict__ fail) {
+  if (threadIdx.x < 8) fail[threadIdx.x] = 0;
+}
+
 template <int NT>
 int launch_gram(const float* t, long long t_b, long long t_r, int n_rows, int d, int B, float* jtj, float* logdet,
                 float* l1_off, float* l1_diag, int* info, int* fail, hipStream_t s) {
@@ -218,8 +222,10 @@ extern "C" int cmf_gram_cholesky(const float* t, long long t_b, long long t_r, i
   if (n_rows <= 0 || B <= 0 || d <= 0 || d > nc || nc % 16 || nc > 128) return CMF_EINVAL;
   if ((t_b | t_r) % 4 || (uintptr_t)t % 16) return CMF_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(fail, 0, 8 * sizeof(int), s);
-  if (e != hipSuccess) return (int)e;
+  // A kernel node, not hipMemsetAsync: a captured 32-byte memset node replayed with garbage from the second
+  // hipGraphLaunch on (ROCm 7.2, observed as pointer-like values in the flags), which silently armed every retry.
+  hipLaunchKernelGGL(zero_flags_kernel, dim3(1), dim3(64), 0, s, fail);
+  CMF_LAUNCH_CHECK();
 #define CMF_GRAM_CASE(N) \
   case N: return launch_gram<N>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
   switch (nc / 16) {
