@@ -19,13 +19,15 @@
 namespace {
 
 constexpr int CIC = 8;
-constexpr int SLOTS_W = 4;  // column blocks per wave
 
-template <int TAPS, int COT, int NXB>
+// SLOTS_W = column blocks (16 pixels each) per wave: 4 normally; 1 for 1x1 layers whose grid would otherwise
+// underfill the chip (an MLP layer over B = 4096 samples is only 16 tiles of 256 samples).
+template <int TAPS, int COT, int NXB, int SLOTS_W>
 struct PCfg {
   static constexpr int ROWS = (TAPS == 9) ? 16 / NXB : 1;
   static constexpr int ROWS_H = (TAPS == 9) ? ROWS + 2 : 1;
-  static constexpr int RS = (TAPS == 9) ? 16 * NXB + 2 : 256;       // LDS row stride (dwords)
+  static constexpr int PIX1 = 64 * SLOTS_W;                          // flat pixels per workgroup (1x1)
+  static constexpr int RS = (TAPS == 9) ? 16 * NXB + 2 : PIX1;       // LDS row stride (dwords)
   static constexpr int XS_RAW = ROWS_H * RS;
   static constexpr int XS_CI = ((XS_RAW + 15) / 32) * 32 + 16;      // >= XS_RAW and == 16 (mod 32)
   static constexpr int WS_CI = (COT % 2) ? COT * 16 : COT * 16 + 16;
@@ -37,10 +39,11 @@ struct PCfg {
   static constexpr int NWIT = (NW_ITEMS + 255) / 256;
 };
 
-template <int TAPS, int COT, int NXB>
+template <int TAPS, int COT, int NXB, int SLOTS_W>
 __global__ __launch_bounds__(256, 2) void conv_primal_kernel(cmf_conv_primal_args a, int tiles_x, int ncog,
                                                                int cin_pad) {
-  using C = PCfg<TAPS, COT, NXB>;
+  using C = PCfg<TAPS, COT, NXB, SLOTS_W>;
+  static_assert(TAPS == 1 || SLOTS_W == 4, "3x3 tiles are 16 slots");
   static_assert(C::XS_CI >= C::XS_RAW && C::XS_CI % 32 == 16, "LDS channel stride");
   __shared__ __attribute__((aligned(16))) float smem[C::XS_FLOATS + C::WS_FLOATS];
   float* Xs = smem;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv_primal_kernel(cmf_conv_primal_arg
     y0 = C::ROWS * (tile / tiles_x);
     x0 = 16 * NXB * (tile % tiles_x);
   } else {
-    p0 = tile * 256;
+    p0 = tile * C::PIX1;
   }
   const int x_c = (int)a.x_c, x_px = (int)a.x_px, f_c = (int)a.f_c, f_px = (int)a.f_px;
   const float* xb = a.x + (long long)b * a.x_b;
@@ -196,31 +199,31 @@ __global__ __launch_bounds__(256, 2) void conv_primal_kernel(cmf_conv_primal_arg
   }
 }
 
-template <int TAPS, int COT, int NXB>
+template <int TAPS, int COT, int NXB, int SLOTS_W>
 int launch(const cmf_conv_primal_args& a, hipStream_t s) {
-  using C = PCfg<TAPS, COT, NXB>;
+  using C = PCfg<TAPS, COT, NXB, SLOTS_W>;
   int tiles, tiles_x = 1;
   if (TAPS == 9) {
     tiles_x = cmf_ceil_div(a.W, 16 * NXB);
     tiles = tiles_x * cmf_ceil_div(a.H, C::ROWS);
   } else {
-    tiles = cmf_ceil_div((long long)a.H * a.W, 256);
+    tiles = cmf_ceil_div((long long)a.H * a.W, C::PIX1);
   }
   const int ncog = cmf_ceil_div(a.cout, 64), cin_pad = (a.cin + 7) / 8 * 8;
-  hipLaunchKernelGGL((conv_primal_kernel<TAPS, COT, NXB>), dim3(tiles, ncog, a.B), dim3(256), 0, s, a, tiles_x, ncog,
-                     cin_pad);
+  hipLaunchKernelGGL((conv_primal_kernel<TAPS, COT, NXB, SLOTS_W>), dim3(tiles, ncog, a.B), dim3(256), 0, s, a, tiles_x,
+                     ncog, cin_pad);
   CMF_LAUNCH_CHECK();
   return 0;
 }
 
-template <int TAPS, int NXB>
+template <int TAPS, int NXB, int SLOTS_W>
 int launch_cot(const cmf_conv_primal_args& a, hipStream_t s) {
   const int cot = (a.cout >= 64) ? 4 : (a.cout + 15) / 16;
   switch (cot) {
-    case 1: return launch<TAPS, 1, NXB>(a, s);
-    case 2: return launch<TAPS, 2, NXB>(a, s);
-    case 3: return launch<TAPS, 3, NXB>(a, s);
-    default: return launch<TAPS, 4, NXB>(a, s);
+    case 1: return launch<TAPS, 1, NXB, SLOTS_W>(a, s);
+    case 2: return launch<TAPS, 2, NXB, SLOTS_W>(a, s);
+    case 3: return launch<TAPS, 3, NXB, SLOTS_W>(a, s);
+    default: return launch<TAPS, 4, NXB, SLOTS_W>(a, s);
   }
 }
 
@@ -243,6 +246,8 @@ extern "C" int cmf_conv_primal(const cmf_conv_primal_args* ap, void* stream) {
       a.B > 65535 || HW > (1LL << 30))
     return CMF_ERANGE;
   hipStream_t s = (hipStream_t)stream;
-  if (a.taps == 9) return (a.W <= 16) ? launch_cot<9, 1>(a, s) : launch_cot<9, 2>(a, s);
-  return launch_cot<1, 1>(a, s);
+  if (a.taps == 9) return (a.W <= 16) ? launch_cot<9, 1, 4>(a, s) : launch_cot<9, 2, 4>(a, s);
+  // 1x1: 256-pixel tiles unless that leaves most of the 256 CUs idle, then 64-pixel tiles
+  const long long blocks256 = (HW + 255) / 256 * ((a.cout + 63) / 64) * a.B;
+  return blocks256 >= 512 ? launch_cot<1, 1, 4>(a, s) : launch_cot<1, 1, 1>(a, s);
 }
