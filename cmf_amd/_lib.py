@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcmf_amd.so")
 
-F_NONE, F_RELU, F_TANH, F_RAW = 0, 1, 2, 3
+F_NONE, F_RELU, F_TANH, F_RAW, F_SELF_RELU = 0, 1, 2, 3, 4
 O_NONE, O_TANH, O_STANH = 0, 1, 2
 
 _fp = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
@@ -23,7 +23,8 @@ class ConvTangentArgs(C.Structure):
                 ("w", _fp),
                 ("y", _fp), ("y_np", _ll), ("y_co", _ll), ("y_px", _ll),
                 ("r", _fp), ("r_np", _ll), ("r_co", _ll), ("r_px", _ll),
-                ("np", _i), ("cin", _i), ("cout", _i), ("H", _i), ("W", _i), ("nc", _i), ("taps", _i)]
+                ("np", _i), ("cin", _i), ("cout", _i), ("H", _i), ("W", _i), ("nc", _i), ("taps", _i),
+                ("bias", _fp), ("f_group", _i)]
 
 
 class ConvPrimalArgs(C.Structure):
@@ -44,6 +45,7 @@ SIGNATURES = {
     "cmf_conv_tangent": (_i, [C.POINTER(ConvTangentArgs), _fp]),
     "cmf_pack_weight_bf16x3": (_i, [_fp, _fp, _i, _i, C.POINTER(_ll), _fp]),
     "cmf_conv_tangent_bf16x3": (_i, [C.POINTER(ConvTangentArgs), _fp]),
+    "cmf_primal_regroup": (_i, [_fp, _fp, _i, _ll, _i, _fp]),
     "cmf_conv_primal": (_i, [C.POINTER(ConvPrimalArgs), _fp]),
     "cmf_acl_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "cmf_acl_tangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _fp]),

@@ -128,12 +128,12 @@ class AffineCouplingBijection(Bijection):
 
     # engine-level steps (in place on z / T) ----------------------------------------------------
     def encode_(self, z, lj=None):
-        y, _, _ = E.net_primal(self.net, z, self.view(z.device))
+        y, _, _ = E.net_primal(self.net, z, self.view(z.device), need_acts=False)
         E.acl_primal(z, y, self.maps(z.device), decode=False, lj=lj)
 
     def decode_(self, z, T=None, lj=None):
         view = self.view(z.device)
-        y, g, acts = E.net_primal(self.net, z, view)
+        y, g, acts = E.net_primal(self.net, z, view, need_acts=T is not None)
         if T is not None:
             YT = E.net_tangent(self.net, T, view, acts)
             E.acl_tangent(T, YT, z, y, g, self.maps(z.device))      # uses z BEFORE the primal update

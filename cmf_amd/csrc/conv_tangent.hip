@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
   }
 
   const float* xb = a.x + (long long)np * a.x_np + slice * 16;
-  const float* fb = a.f ? a.f + (long long)np * a.f_np : nullptr;
+  const int fgrp = a.f_group > 1 ? a.f_group : 1;
+  const float* fb = a.f ? a.f + (long long)(np / fgrp) * a.f_np + (np % fgrp) : nullptr;
   const float* wb = a.w + (long long)cog * TAPS * cin_pad * 64;  // one co-group slab: < 2^31 floats
 
   // ---- per-thread staging plan (chunk independent part) ----
@@ -119,10 +120,11 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
 #pragma unroll
   for (int it = 0; it < C::NXIT; ++it) fr[it] = 0.f;   // stays 0 when fmode == NONE (never loaded)
   // NONE: 1   RELU: [f>0]   TANH: 1 - f^2   RAW: f
-  const float fc0 = (a.fmode == CMF_F_NONE || a.fmode == CMF_F_TANH) ? 1.f : 0.f;
+  const float fc0 = (a.fmode == CMF_F_NONE || a.fmode == CMF_F_TANH || a.fmode == CMF_F_SELF_RELU) ? 1.f : 0.f;
   const float fc1 = (a.fmode == CMF_F_RELU) ? 1.f : 0.f;
   const float fc2 = (a.fmode == CMF_F_RAW) ? 1.f : 0.f;
   const float fc3 = (a.fmode == CMF_F_TANH) ? -1.f : 0.f;
+  const bool selfrelu = a.fmode == CMF_F_SELF_RELU;          // elementwise relu of the loaded values themselves
   unsigned okchunk = 0;                  // okbits restricted to channels < cin for the chunk being prefetched
 
   // Loads are unconditional and always consumed (a select on validity lets hipcc sink a load into a branch +
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
       const unsigned off = ok ? 4u * (unsigned)(ci0 * x_ci) + (unsigned)xo[it] : 0u;
       xr[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(xb) + off);
     }
-    if (a.fmode != CMF_F_NONE) {
+    if (a.fmode != CMF_F_NONE && a.fmode != CMF_F_SELF_RELU) {
 #pragma unroll
       for (int it = 0; it < C::NXIT; ++it) {
         const unsigned off = ((okchunk >> it) & 1u) ? 4u * (unsigned)(ci0 * f_ci) + (unsigned)fo[it] : 0u;
@@ -166,7 +168,12 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
         // branch-free multiplier: ok * (c0 + c1*[f>0] + c2*f + c3*f*f) with wave-uniform mode coefficients
         const float f = fr[it];
         const float m = (((okcommit >> it) & 1u) ? 1.f : 0.f) * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
-        *reinterpret_cast<f32x4*>(Xs + ci * C::XS_CI + pix * 16 + q * 4) = xr[it] * m;
+        f32x4 xv = xr[it];
+        if (selfrelu) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) xv[c] = fmaxf(xv[c], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(Xs + ci * C::XS_CI + pix * 16 + q * 4) = xv * m;
       }
     }
 #pragma unroll
@@ -263,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
         for (int r = 0; r < 4; ++r) {
           if (is_full || (co0 + c * 16 + r) < a.cout) {
             float v = acc[p][c][r];
+            if (a.bias) v += a.bias[co0 + c * 16 + r];
             if (has_res) v += rp[(c * 16 + r) * r_co];
             yp[(c * 16 + r) * y_co] = v;
           }
@@ -319,7 +327,8 @@ extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
   if (a.taps != 1 && a.taps != 9) return CMF_EINVAL;
   if (a.nc <= 0 || a.nc % 16) return CMF_EINVAL;
-  if (a.fmode < CMF_F_NONE || a.fmode > CMF_F_RAW || (a.fmode != CMF_F_NONE && !a.f)) return CMF_EINVAL;
+  if (a.fmode < CMF_F_NONE || a.fmode > CMF_F_SELF_RELU) return CMF_EINVAL;
+  if (a.fmode != CMF_F_NONE && a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
   // 16-byte vector loads of the column slices
   if ((a.x_np | a.x_ci | a.x_px) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
   const long long HW = (long long)a.H * a.W;

@@ -89,7 +89,9 @@ __device__ __forceinline__ int xslot(int col, int pix) { return (((col & 3) << 2
 //               activation-derivative factor, hi/lo split -> LDS stage.  Their chunk stream runs across item
 //               boundaries, so only the first chunk of the launch sees memory latency.
 // Two LDS stages (2 x 56 KiB), ONE barrier per 8-channel chunk; both roles execute the same number of barriers.
-template <int COT, int PXW>
+// SELF = the input's own elementwise relu is applied on load (primal data in the column slots); a compile-time switch:
+// as a run-time select it made hipcc spill 77 VGPRs in the loader's commit.
+template <int COT, int PXW, bool SELF>
 __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
                                                                        int nslices, int ncog, int total) {
   using C = BCfg<COT, PXW>;
@@ -139,10 +141,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     const int q = lt & 3, pix = lt >> 2;
     const int hy = pix / C::TWH, hx = pix % C::TWH;
     // NONE: 1   RELU: [f>0]   TANH: 1 - f^2   RAW: f      as  okf * (c0 + c1*[f>0] + c2*f + c3*f*f)
-    const float fc0 = (a.fmode == CMF_F_NONE || a.fmode == CMF_F_TANH) ? 1.f : 0.f;
+    const float fc0 = (a.fmode == CMF_F_NONE || a.fmode == CMF_F_TANH || a.fmode == CMF_F_SELF_RELU) ? 1.f : 0.f;
     const float fc1 = (a.fmode == CMF_F_RELU) ? 1.f : 0.f;
     const float fc2 = (a.fmode == CMF_F_RAW) ? 1.f : 0.f;
     const float fc3 = (a.fmode == CMF_F_TANH) ? -1.f : 0.f;
+    const bool has_f = a.fmode != CMF_F_NONE && a.fmode != CMF_F_SELF_RELU;
+    const int fgrp = a.f_group > 1 ? a.f_group : 1;
 
     // prefetch cursor: which (work item, chunk) the next prefetch fetches, with that item's addressing state.
     // Bases are wave-uniform; per-lane offsets are unsigned 32-bit BYTE offsets (SGPR-base loads, no 64-bit per-lane
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       decode(item, tile, slice, cog, np);
       const int y0 = 2 * (tile / tiles_x), x0 = C::TW * (tile % tiles_x);
       xb = a.x + (long long)np * a.x_np + slice * 16;
-      fb = a.f ? a.f + (long long)np * a.f_np : a.x;
+      fb = a.f ? a.f + (long long)(np / fgrp) * a.f_np + (np % fgrp) : a.x;
       wb = reinterpret_cast<const unsigned char*>(a.w) + (long long)cog * nchunks * C::W_CHUNK_BYTES;
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
       const bool ok = lt < C::NX_ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         r.x[j] = f32x4{(float)off, 1.f, 2.f, 3.f};
 #endif
       }
-      if (a.fmode != CMF_F_NONE) {
+      if (has_f) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const unsigned off = 4u * (unsigned)((ch * 8 + j) * f_ci) + fo;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
           const float f = r.f[j];
           const float m = r.okf * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[j][c] = r.x[j][c] * m;
+          for (int c = 0; c < 4; ++c) v[j][c] = (SELF ? fmaxf(r.x[j][c], 0.f) : r.x[j][c]) * m;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                              // column q*4 + c: 8 channels -> 16 B hi + 16 B lo
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     const int gy = it.y0 + wrow, gx = it.x0 + p;
 #pragma unroll
     for (int c = 0; c < CW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (it.r && gy < a.H && gx < a.W) {
+    if (it.r && gy < a.H && gx < a.W) {                 // loads go straight into the accumulators (no temporaries)
       const float* rp = it.r + (gy * a.W + gx) * r_px + it.co0 * r_co;
 #pragma unroll
       for (int c = 0; c < CW; ++c)
@@ -358,7 +362,10 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     float* yp = it.y + (gy * a.W + gx) * y_px + it.co0 * y_co;
 #pragma unroll
     for (int c = 0; c < CW; ++c)
-      if (it.full || (it.co0 + c * 16) < a.cout) *reinterpret_cast<f32x4*>(yp + (c * 16) * y_co) = acc[p][c];
+      if (it.full || (it.co0 + c * 16) < a.cout) {
+        const float bv = a.bias ? a.bias[it.co0 + c * 16] : 0.f;     // per-channel constant (primal bias), added at store
+        *reinterpret_cast<f32x4*>(yp + (c * 16) * y_co) = acc[p][c] + bv;
+      }
   };
 
   // One 8-channel chunk from LDS stage `stage`.  LAST = the item's final chunk: pixel p's accumulators are final
@@ -453,14 +460,14 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned 
   out[i] = __builtin_bit_cast(unsigned short, r);
 }
 
-template <int COT, int PXW>
+template <int COT, int PXW, bool SELF>
 int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   using C = BCfg<COT, PXW>;
   const int tiles_x = cmf_ceil_div(a.W, 2 * PXW), tiles = tiles_x * cmf_ceil_div(a.H, 2);
   const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
-  auto k = conv_tangent_bf16x3_kernel<COT, PXW>;
+  auto k = conv_tangent_bf16x3_kernel<COT, PXW, SELF>;
   constexpr int lds = 2 * C::BUF_BYTES;
   static int n_cu = 0;                          // idempotent initialisation; a benign race at worst repeats it
   if (n_cu == 0) {
@@ -479,7 +486,8 @@ int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
 
 template <int PXW>
 int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
-  return (a.cout > 32) ? launch<4, PXW>(a, s) : launch<2, PXW>(a, s);   // co tiles per workgroup: 64 or 32 channels
+  if (a.fmode == CMF_F_SELF_RELU) return (a.cout > 32) ? launch<4, PXW, true>(a, s) : launch<2, PXW, true>(a, s);
+  return (a.cout > 32) ? launch<4, PXW, false>(a, s) : launch<2, PXW, false>(a, s);   // co tiles per workgroup: 64 / 32 channels
 }
 
 inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 29); }   // element offsets; x4 bytes must fit 32 bits
@@ -503,7 +511,8 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   const cmf_conv_tangent_args& a = *ap;
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
   if (a.taps != 9 || a.cin % 8 || a.nc <= 0 || a.nc % 16) return CMF_EINVAL;
-  if (a.fmode < CMF_F_NONE || a.fmode > CMF_F_RAW || (a.fmode != CMF_F_NONE && !a.f)) return CMF_EINVAL;
+  if (a.fmode < CMF_F_NONE || a.fmode > CMF_F_SELF_RELU) return CMF_EINVAL;
+  if (a.fmode != CMF_F_NONE && a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
   if ((a.x_np | a.x_ci | a.x_px) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
   if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;            // 16-byte stores
   if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;    // 16-byte residual loads

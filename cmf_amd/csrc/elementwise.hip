@@ -129,6 +129,24 @@ __global__ void seed_tangent_kernel(float* __restrict__ t, long long t_b, long l
   reinterpret_cast<f32x4*>(t + b * t_b + (long long)r * t_r)[c4] = v;
 }
 
+// (B, N) <-> (B/16, N, 16): 16 x 16 transposes through registers of one 16-lane group
+__global__ void primal_regroup_kernel(const float* __restrict__ in, float* __restrict__ out, int B, long long N,
+                                      int to_grouped) {
+  __shared__ float tile[16][17];
+  const int g = blockIdx.y;                                  // sample group
+  const long long n0 = (long long)blockIdx.x * 16;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;    // 256 threads = 16 x 16
+  if (to_grouped) {
+    if (n0 + tx < N) tile[ty][tx] = in[((long long)g * 16 + ty) * N + n0 + tx];       // row = sample, col = element
+    __syncthreads();
+    if (n0 + ty < N) out[((long long)g * N + n0 + ty) * 16 + tx] = tile[tx][ty];
+  } else {
+    if (n0 + ty < N) tile[ty][tx] = in[((long long)g * N + n0 + ty) * 16 + tx];       // row = element, col = sample
+    __syncthreads();
+    if (n0 + tx < N) out[((long long)g * 16 + ty) * N + n0 + tx] = tile[tx][ty];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pre-head: one block per sample
 __global__ void prehead_kernel(const float* __restrict__ x, const float* __restrict__ u, float* __restrict__ y,
@@ -227,6 +245,14 @@ int cmf_pack_weight(const float* w, float* out, int cout, int cin, int taps, int
   if (!w) return CMF_EINVAL;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, w, out, cout, cin,
                      taps, transpose, ncin_pad, total);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+int cmf_primal_regroup(const float* in, float* out, int B, long long N, int to_grouped, void* stream) {
+  if (!in || !out || B <= 0 || B % 16 || N <= 0 || (N + 15) / 16 > 0x7fffffffLL) return CMF_EINVAL;
+  hipLaunchKernelGGL(primal_regroup_kernel, dim3((unsigned)((N + 15) / 16), B / 16), dim3(256), 0, (hipStream_t)stream, in,
+                     out, B, N, to_grouped);
   CMF_LAUNCH_CHECK();
   return 0;
 }

@@ -35,6 +35,7 @@ extern "C" {
 #define CMF_F_RELU 1      /* (f > 0)           relu'  : jvp_layers.py:40                 */
 #define CMF_F_TANH 2      /* 1 - f*f           tanh'  with f = tanh output: :42-44       */
 #define CMF_F_RAW  3      /* f itself          checkerboard mask: acl.py:54              */
+#define CMF_F_SELF_RELU 4 /* relu of the input itself, elementwise (primal data carried in the column slots) */
 
 /* primal epilogues */
 #define CMF_O_NONE  0
@@ -68,6 +69,10 @@ typedef struct {
   float* y;       long long y_np, y_co, y_px;
   const float* r; long long r_np, r_co, r_px;   /* residual (same shape as y) or NULL                 */
   int np, cin, cout, H, W, nc, taps;
+  const float* bias;                            /* per-output-channel constant added to every column, or NULL  */
+  int f_group;                                  /* >1: the factor tensor is sample-grouped: element (np, ci, px)
+                                                   lives at f[(np / f_group)*f_np + ci*f_ci + px*f_px + np % f_group]
+                                                   (primal activations kept in the "16 samples as columns" layout) */
 } cmf_conv_tangent_args;
 int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
 
@@ -100,6 +105,10 @@ typedef struct {
   int B, cin, cout, H, W, taps;
 } cmf_conv_primal_args;
 int cmf_conv_primal(const cmf_conv_primal_args* a, void* stream);
+
+/* (B, N) row-major  <->  (B/G, N, G) sample-grouped layout, G = 16: the primal hidden activations of the ResNet
+ * couplers run through the tangent kernels with 16 samples in the 16 column slots (B % 16 == 0).             */
+int cmf_primal_regroup(const float* in, float* out, int B, long long N, int to_grouped, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Affine coupling transforms (acl.py:43-66, :101-146), in place on the primal / tangent tensors.

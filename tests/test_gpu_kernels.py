@@ -85,3 +85,36 @@ def test_gram_cholesky(N, d, layout):
     diag = torch.diagonal(G, dim1=1, dim2=2).abs().sum(1)
     assert rel(gr.l1_diag, diag) < 1e-5 and rel(gr.l1_off, G.abs().sum((1, 2)) - diag) < 1e-5
     assert gr.fail.tolist()[0] == 0
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("H,W", [(14, 14), (28, 28), (5, 14)])
+def test_conv_tangent_primal_in_column_slots(H, W, precision, monkeypatch):
+    """16 samples in the 16 column slots: elementwise relu on load (SELF_RELU), bias, residual; and a tangent launch
+    reading its relu' factor from that sample-grouped primal tensor (f_group = 16)."""
+    from cmf_amd import engine as E
+    monkeypatch.setattr(E, "TANGENT_PRECISION", precision)
+    gen = torch.Generator().manual_seed(H * W)
+    B, C, HW = 32, 64, H * W
+    x = torch.randn(B, C, H, W, generator=gen)
+    w = torch.randn(C, C, 3, 3, generator=gen) / 24
+    bias = torch.randn(C, generator=gen)
+    res = torch.randn(B, C, H, W, generator=gen)
+    want = F.conv2d(torch.relu(x), w, bias, padding=1) + res
+    xg, rg = E.primal_regroup(x.cuda(), True), E.primal_regroup(res.cuda(), True)
+    assert torch.equal(E.primal_regroup(xg.view(B // 16, -1), False).view(B, C, H, W).cpu(), x)
+    yg = torch.empty_like(xg)
+    wd = torch.nn.Parameter(w.cuda())
+    pn = (C * HW * 16, HW * 16, 16)
+    E.conv_tangent(xg, 0, *pn, wd, 9, yg, *pn, B // 16, C, C, H, W, 16, fmode=E.F_SELF_RELU, bias=bias.cuda(), res_t=rg)
+    got = E.primal_regroup(yg.view(B // 16, -1), False).view(B, C, H, W)
+    assert rel(got, want) < 2e-5
+    # tangent pass with the grouped primal as factor source
+    nc = 16
+    v = torch.randn(B, C, H, W, nc, generator=gen)
+    wantv = F.conv2d(((x > 0).float().unsqueeze(-1) * v).permute(0, 4, 1, 2, 3).reshape(B * nc, C, H, W), w, padding=1)
+    wantv = wantv.reshape(B, nc, C, H, W).permute(0, 2, 3, 4, 1)
+    yv = torch.empty(B, C, H, W, nc, device="cuda")
+    E.conv_tangent(v.cuda(), 0, C * HW * nc, HW * nc, nc, wd, 9, yv, C * HW * nc, HW * nc, nc, B, C, C, H, W, nc,
+                   fmode=E.F_RELU, f=xg, f_np=C * HW * 16, f_ci=HW * 16, f_px=16, f_group=16)
+    assert rel(yv, wantv) < 2e-5
