@@ -15,39 +15,87 @@
 // fail[0] when any sample hits a non-positive pivot; cmf_cholesky_retry(a) is enqueued unconditionally
 // and exits at once unless fail[a-1] is set.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int KC = 32;  // J rows per LDS slab
 
 
-// In-place lower Cholesky of the leading d x d block of G (row stride ldg) by the whole workgroup.
-// Returns 0 or (k+1) for a non-positive / non-finite pivot at column k; *logdet = 2*sum(log L_kk).
+// Log-det by symmetric elimination on the lower triangle of the leading d x d block of G (row stride ldg), whole
+// workgroup (256 threads as a 16 x 16 grid, no index divisions).  Only the pivots are needed: p_k = G_kk after the
+// first k eliminations equals L_kk^2 of the Cholesky factor the reference computes (non_square.py:282,293-294), so
+// logdet = sum_k log p_k and "pivot <= 0 or not finite" is exactly torch.linalg.cholesky's failure condition.  No
+// square roots, no column scaling, ONE barrier per step:  G_ij -= G_ik * G_jk / p_k  for k < j <= i.
+// Returns 0 or (k+1) for a bad pivot at column k.
 __device__ int block_cholesky(float* G, int ldg, int d, float* logdet) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
   float ld = 0.f;
   int info = 0;
   for (int k = 0; k < d; ++k) {
-    const float piv = G[k * ldg + k];
-    if (!(piv > 0.f) || !(piv < 3.0e38f)) {   // uniform: every thread reads the same LDS word
+    const float piv = G[k * ldg + k];            // uniform: every thread reads the same LDS word
+    if (!(piv > 0.f) || !(piv < 3.0e38f)) {
       info = k + 1;
       break;
     }
-    const float lkk = sqrtf(piv);
-    ld += logf(lkk);
-    const float inv = 1.f / lkk;
-    __syncthreads();                           // everyone has read the pivot before it is overwritten
-    for (int i = k + 1 + tid; i < d; i += nt) G[i * ldg + k] *= inv;
-    if (tid == 0) G[k * ldg + k] = lkk;
-    __syncthreads();
-    const int m = d - k - 1;
-    for (int idx = tid; idx < m * m; idx += nt) {
-      const int i = k + 1 + idx / m, j = k + 1 + idx % m;
-      if (j <= i) G[i * ldg + j] -= G[i * ldg + k] * G[j * ldg + k];
+    ld += logf(piv);
+    for (int i = k + 1 + ti; i < d; i += 16) {
+      const float gik = G[i * ldg + k] / piv;      // IEEE division: an exactly singular matrix must give an exact 0 pivot
+      for (int j = k + 1 + tj; j <= i; j += 16) G[i * ldg + j] -= gik * G[j * ldg + k];
     }
-    __syncthreads();
+    __syncthreads();                             // column k is read by this step only; row/col k+1 is final after it
   }
-  *logdet = 2.f * ld;
+  *logdet = ld;
+  return info;
+}
+
+// The same elimination with the matrix in REGISTERS: thread (ti, tj) of the 16 x 16 grid keeps the NT x NT elements
+// (ti + 16a, tj + 16c).  Per step only column k goes through LDS (double-buffered: one barrier per step): its owners
+// publish it, everyone reads the pivot, NT row factors and NT column values and updates its registers.  For j <= i the
+// arithmetic is that of block_cholesky (G_ij -= (G_ik / p_k) G_jk); the mirror half is computed but never read.
+typedef unsigned int u32x4 __attribute__((vector_size(16)));   // the type raw_buffer_load_b128 returns
+
+template <int NT>
+__device__ int block_cholesky_reg(const float* G, int ldg, int d, float* colbuf, float* logdet) {
+  constexpr int NC = NT * 16;
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  float g[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int c = 0; c < NT; ++c) g[a][c] = G[(ti + 16 * a) * ldg + tj + 16 * c];
+  float ld = 0.f;
+  int info = 0;
+#pragma unroll
+  for (int c0 = 0; c0 < NT; ++c0) {
+    if (info) break;
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = c0 * 16 + kk;
+      if (k >= d) break;
+      float* cb = colbuf + (k & 1) * NC;
+      if (tj == kk) {
+#pragma unroll
+        for (int a = 0; a < NT; ++a) cb[ti + 16 * a] = g[a][c0];
+      }
+      __syncthreads();
+      const float piv = cb[k];
+      if (!(piv > 0.f) || !(piv < 3.0e38f)) {
+        info = k + 1;
+        break;
+      }
+      ld += logf(piv);
+      float l[NT], r[NT];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) l[a] = cb[ti + 16 * a] / piv;
+#pragma unroll
+      for (int c = 0; c < NT; ++c) r[c] = cb[tj + 16 * c];
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) g[a][c] -= l[a] * r[c];
+    }
+  }
+  *logdet = ld;
   return info;
 }
 
@@ -193,6 +241,147 @@ __global__ __launch_bounds__(256) void chol_retry_kernel(float* __restrict__ jtj
   report(b, inf, ld, logdet, info, fail + attempt);
 }
 
+// Gram without LDS staging or barriers, for NC = 16*NT with NT a multiple of 4 (d <= 64: NT = 4, d <= 128: NT = 8).
+// A lane of lane group kq loads NT consecutive columns of row k0 + kq (NT/4 float4: one 4-row group of the J panel is
+// 16*NT*4*4 bytes, fully coalesced) and uses component t as its A and B operand element of column tile t: tile t then
+// holds the columns {NT*i + t}, a permutation that is the same on both sides of J^T J and is undone when G is written.
+// NT = 8: wave w accumulates row tiles it = w, w+4 against all column tiles over ALL rows (the four waves re-read the
+// same lines: L1 hits).  NT = 4: all 16 tiles fit one wave's registers, so the ROWS are dealt to the four waves instead
+// (4x the bytes in flight per CU -- with shared rows the kernel was load-latency-bound at ~1 TB/s) and the four partial
+// Grams are parked in four LDS planes and summed on the way out (ds_add_f32 costs ~64 cycles per wave instruction
+// here: measured +44 us).  Loads run PF groups ahead in registers.
+template <int NT>
+__global__ __launch_bounds__(256) void gram_chol_direct_kernel(const float* __restrict__ t, long long t_b, long long t_r,
+                                                                int n_rows, int d, float* __restrict__ jtj,
+                                                                float* __restrict__ logdet, float* __restrict__ l1_off,
+                                                                float* __restrict__ l1_diag, int* __restrict__ info,
+                                                                int* __restrict__ fail) {
+  static_assert(NT % 4 == 0, "whole float4 per lane");
+  constexpr bool KSPLIT = NT == 4;                 // deal 4-row groups to waves; every wave owns all NT x NT tiles
+  constexpr int NC = NT * 16, LDG = NC + 1, NI = KSPLIT ? NT : NT / 4, NV = NT / 4, PF = 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* G = smem;                                 // [NC][LDG]
+  __shared__ float red[16];
+  __shared__ float colbuf[2 * NC];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, cl = lane & 15;
+  const int b = blockIdx.x;
+  const float* tb = t + (long long)b * t_b + cl * NT;           // this lane's NT columns
+
+  f32x4 acc[NI][NT];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ngroups_all = (n_rows + 3) >> 2;
+  const int ngroups = KSPLIT ? (ngroups_all + 3 - wave) / 4 : ngroups_all;      // this wave's share
+  // Rows come through a bounds-checked buffer descriptor over this sample's panel: a row past n_rows reads as zeros, so
+  // there is no select after the load (a select made hipcc wait for all PF loads at the top of every iteration).
+  // The per-group advance lives in the DESCRIPTOR (scalar base += group, records -= group) and the lane offset VGPR is
+  // loop-invariant: a per-step VGPR offset was allocated inside the ring slot being refilled, and rewriting it for
+  // the next step then waited for that load (vmcnt(0) every step).
+  const char* panel = reinterpret_cast<const char*>(t + (long long)b * t_b);
+  const int panel_bytes = (int)((long long)n_rows * t_r * 4);
+  const int row_bytes = (int)t_r * 4;
+  const int group_bytes = (KSPLIT ? 16 : 4) * row_bytes;
+  const int voff = ((KSPLIT ? wave : 0) * 4 + kq) * row_bytes + cl * NT * 4;
+  int goff = 0;                                    // wave-uniform byte offset of the next group to fetch
+  u32x4 ring[PF][NV];
+  auto load = [&](int slot) {
+    const int left = panel_bytes - goff;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(panel + goff), 0, left > 0 ? left : 0, 0x00020000);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ring[slot][v] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16 * v, 0, 0);
+    goff += group_bytes;
+  };
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    load(s);
+    __builtin_amdgcn_sched_barrier(0);             // issue in slot order, or the loop-header wait degrades to vmcnt(0)
+  }
+  // W = the wave's first row tile as a compile-time constant: a run-time comp[wave + 4i] became v_cndmask temporaries
+  // that were again allocated inside in-flight ring slots.
+  auto run = [&](auto wc) {
+    constexpr int W = decltype(wc)::value;
+    for (int g0 = 0; g0 < ngroups; g0 += PF) {
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        float comp[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const unsigned u = ring[s][j >> 2][j & 3];     // via a scalar: bit_cast of a vector ELEMENT lvalue reads lane 0
+          comp[j] = __builtin_bit_cast(float, u);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp[KSPLIT ? i : W + 4 * i], comp[j], acc[i][j], 0, 0, 0);
+        load(s);                                   // refill this slot for PF groups ahead
+        __builtin_amdgcn_sched_barrier(0);         // keep consume(s) -> refill(s) order: waits become vmcnt(PF-1)
+      }
+    }
+  };
+  if (KSPLIT || wave == 0) run(std::integral_constant<int, 0>{});
+  else if (wave == 1) run(std::integral_constant<int, 1>{});
+  else if (wave == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 3>{});
+
+  // park G in LDS, undoing the column permutation: tile element (row kq*4 + r, col cl) of tile (it, jt) is
+  // G[NT*(kq*4 + r) + it][NT*cl + jt]
+  constexpr int PLANE = NC * LDG;
+  float* Gw = KSPLIT ? G + wave * PLANE : G;       // KSPLIT: one partial-Gram plane per wave
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int it = KSPLIT ? i : wave + 4 * i;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Gw[(NT * (kq * 4 + r) + it) * LDG + NT * cl + j] = acc[i][j][r];
+  }
+  __syncthreads();
+
+  float so = 0.f, sd = 0.f;
+  float* gout = jtj + (long long)b * d * d;
+  for (int idx = tid; idx < d * d; idx += 256) {
+    const int i = idx / d, j = idx % d;
+    float v = G[i * LDG + j];
+    if (KSPLIT) {
+      v = (v + G[PLANE + i * LDG + j]) + (G[2 * PLANE + i * LDG + j] + G[3 * PLANE + i * LDG + j]);
+      G[i * LDG + j] = v;
+    }
+    gout[idx] = v;
+    if (i == j) sd += fabsf(v); else so += fabsf(v);
+  }
+  so = block_sum(so, red);
+  sd = block_sum(sd, red);
+  if (tid == 0) {
+    l1_off[b] = so;
+    l1_diag[b] = sd;
+  }
+  float ld;
+  __syncthreads();                                 // plane 0 holds the summed Gram
+  const int inf = block_cholesky_reg<NT>(G, LDG, d, colbuf, &ld);
+  report(b, inf, ld, logdet, info, fail + 0);
+}
+
+template <int NT>
+int launch_gram_direct(const float* t, long long t_b, long long t_r, int n_rows, int d, int B, float* jtj, float* logdet,
+                       float* l1_off, float* l1_diag, int* info, int* fail, hipStream_t s) {
+  constexpr int NC = NT * 16;
+  const size_t lds = (size_t)(NC * (NC + 1)) * sizeof(float) * (NT == 4 ? 4 : 1);
+  auto k = gram_chol_direct_kernel<NT>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, dim3(B), dim3(256), lds, s, t, t_b, t_r, n_rows, d, jtj, logdet, l1_off, l1_diag, info, fail);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void zero_flags_kernel(int* __restrict__ fail) {
   if (threadIdx.x < 8) fail[threadIdx.x] = 0;
 }
@@ -226,6 +415,8 @@ extern "C" int cmf_gram_cholesky(const float* t, long long t_b, long long t_r, i
   // hipGraphLaunch on (ROCm 7.2, observed as pointer-like values in the flags), which silently armed every retry.
   hipLaunchKernelGGL(zero_flags_kernel, dim3(1), dim3(64), 0, s, fail);
   CMF_LAUNCH_CHECK();
+  if (nc == 64) return launch_gram_direct<4>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
+  if (nc == 128) return launch_gram_direct<8>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
 #define CMF_GRAM_CASE(N) \
   case N: return launch_gram<N>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
   switch (nc / 16) {

@@ -10,14 +10,14 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None); ap.add_argument("--B", type=int, default=128); ap.add_argument("--hw", type=int, default=28)
 ap.add_argument("--res", type=int, default=1); ap.add_argument("--precision", default="bf16x3"); ap.add_argument("--iters", type=int, default=10)
-ap.add_argument("--fmode", default="relu")
+ap.add_argument("--fmode", default="relu"); ap.add_argument("--nc", type=int, default=64)
 args = ap.parse_args()
 from cmf_amd import _lib
 if args.lib:
     _lib.LIB_PATH = os.path.abspath(args.lib)
 from cmf_amd import engine as E
 E.TANGENT_PRECISION = args.precision
-B, H, nc, ch = args.B, args.hw, 64, 64
+B, H, nc, ch = args.B, args.hw, args.nc, 64
 HW = H * H
 x = torch.randn(B, ch, H, H, nc, device="cuda"); prim = torch.randn(B, ch, H, H, device="cuda")
 res = torch.randn(B, ch, H, H, nc, device="cuda") if args.res else None
