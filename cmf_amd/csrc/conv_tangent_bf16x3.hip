@@ -19,6 +19,7 @@
 //             cmf_pack_weight_bf16x3, so staging is a straight copy.
 // A staging thread owns one (pixel, 4 columns) item: it loads the 8 channels of the octet (8 x 16 B),
 // applies the activation-derivative factor, splits, and writes 4 + 4 ds_write_b128.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -145,82 +146,171 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     const float fc1 = (a.fmode == CMF_F_RELU) ? 1.f : 0.f;
     const float fc2 = (a.fmode == CMF_F_RAW) ? 1.f : 0.f;
     const float fc3 = (a.fmode == CMF_F_TANH) ? -1.f : 0.f;
-    const bool has_f = a.fmode != CMF_F_NONE && a.fmode != CMF_F_SELF_RELU;
+    constexpr bool has_f = !SELF;                                // compile-time: the wait counts below depend on it
+                                                                 // (the launcher rejects fmode NONE without SELF)
     const int fgrp = a.f_group > 1 ? a.f_group : 1;
 
     // prefetch cursor: which (work item, chunk) the next prefetch fetches, with that item's addressing state.
-    // Bases are wave-uniform; per-lane offsets are unsigned 32-bit BYTE offsets (SGPR-base loads, no 64-bit per-lane
-    // addresses kept alive).  Validity is applied arithmetically at commit time: every load is unconditional and
-    // always consumed (a select on validity lets hipcc sink loads into branches + s_waitcnt vmcnt(0)).
+    // Loads are raw buffer loads: descriptor base = the item's wave-uniform base, voffset = the per-lane byte offset
+    // (fixed for the item), soffset = the chunk / channel term (SALU): no VALU address arithmetic per load.  Validity is
+    // applied arithmetically at commit time (every load is unconditional and always consumed).
+    //
+    // The loads are INLINE ASM with hand-counted s_waitcnt: hipcc's own vmcnt bookkeeping collapses on register sets
+    // that stay in flight across loop iterations -- it emitted vmcnt(0..12) in front of every commit (and in front
+    // of address temporaries it had allocated inside in-flight destination registers), i.e. each iteration drained
+    // the prefetch it had just issued and the chunk period contained a full memory latency.  Issue order per
+    // iteration g is fixed:   [X,f of chunk g+3]  commit(g+1)  [W slab of chunk g+2]
+    // so when commit(g+1) starts the loads issued after X,f(g+1) are W(g), X,f(g+2), W(g+1), X,f(g+3), and after
+    // W(g+1) only X,f(g+3).  To keep those counts constant the stream is padded: past the last chunk the cursors stay
+    // on the last chunk (re-fetching it, ~3 chunks per workgroup and launch) instead of skipping loads.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [&](const void* p) {
+      const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+      i32x4 d;
+      d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+      d[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(u >> 32) & 0xffffu));      // stride 0
+      d[2] = -1;                                                                          // no range check
+      d[3] = 0x00020000;
+      return d;
+    };
     int cur_item = 0, cur_ch = 0;
-    const float* xb = a.x;
-    const float* fb = a.x;
-    const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w);
-    unsigned xo = 0, fo = 0;
+    i32x4 xrs = make_rsrc(a.x), frs = xrs, wrs = make_rsrc(a.w);
+    int xo = 0, fo = 0;
     float okf = 0.f;
     auto set_item = [&](int item) {
       int tile, slice, cog, np;
       decode(item, tile, slice, cog, np);
       const int y0 = 2 * (tile / tiles_x), x0 = C::TW * (tile % tiles_x);
-      xb = a.x + (long long)np * a.x_np + slice * 16;
-      fb = a.f ? a.f + (long long)(np / fgrp) * a.f_np + (np % fgrp) : a.x;
-      wb = reinterpret_cast<const unsigned char*>(a.w) + (long long)cog * nchunks * C::W_CHUNK_BYTES;
+      xrs = make_rsrc(a.x + (long long)np * a.x_np + slice * 16);
+      frs = make_rsrc(a.f ? a.f + (long long)(np / fgrp) * a.f_np + (np % fgrp) : a.x);
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
       const bool ok = lt < C::NX_ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       const int gpix = gy * a.W + gx;
       okf = ok ? 1.f : 0.f;
-      xo = ok ? 4u * (unsigned)(gpix * x_px + q * 4) : 0u;
-      fo = ok ? 4u * (unsigned)(gpix * f_px) : 0u;
+      xo = ok ? 4 * (gpix * x_px + q * 4) : 0;
+      fo = ok ? 4 * (gpix * f_px) : 0;
     };
+    // per-thread byte offsets of its W items inside a chunk slab (loop-invariant).  COT == 4 consumes the slab whole
+    // (a linear copy): ONE register, the item stride goes into soffset.
+    constexpr int NWOFF = COT == 4 ? 1 : C::NWIT;
+    int woff[NWOFF];
+    if (COT == 4) {
+      woff[0] = lt << 4;
+    } else {
+#pragma unroll
+      for (int it = 0; it < NWOFF; ++it) {                         // the global slab always has 4 co tiles per K-step
+        int i = lt + 256 * it;
+        i = i < C::NW_ITEMS ? i : C::NW_ITEMS - 1;
+        const int rest = i & 63, t = i >> 6;
+        const int cot = t % COT, s = (t / COT) % 3, hl = t / (3 * COT);
+        woff[it] = (((hl * 3 + s) * 4 + cot) * 64 + rest) << 4;
+      }
+    }
 
     struct Regs {
       f32x4 x[8];
       float f[8];
-      u32x4 w[C::NWIT];
       float okf;
     };
     Regs r0, r1, r2;                                               // chunk g of the stream lives in set g % 3
+    // The weight slab has ONE register set: it comes from L2 (the same 192 KiB for every CU), so it is fetched one chunk
+    // ahead, right after the previous slab was written to LDS (three sets cost 48 more VGPRs and spilled).
+    u32x4 wreg[C::NWIT];
+    int wcur_item = 0, wcur_ch = 0;
+    auto wset_item = [&](int item) {
+      int tile, slice, cog, np;
+      decode(item, tile, slice, cog, np);
+      wrs = make_rsrc(reinterpret_cast<const unsigned char*>(a.w) + (long long)cog * nchunks * C::W_CHUNK_BYTES);
+    };
+    // `s_nop 4` opens every load statement: descriptor / soffset SGPRs may have just been written by SALU code.
+    auto prefetch_w = [&]() {
+      const int wco = wcur_ch * C::W_CHUNK_BYTES;
+#pragma unroll
+      for (int it = 0; it < C::NWIT; ++it) {
+        const int vo = woff[COT == 4 ? 0 : it % NWOFF];
+        const int so = COT == 4 ? wco + it * 4096 : wco;
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(wreg[it]) : "v"(vo), "s"(wrs), "s"(so) : "memory");
+      }
+      if (++wcur_ch == nchunks) {
+        wcur_ch = 0;
+        if (wcur_item + 1 < n_items) wset_item(++wcur_item);
+        else wcur_ch = nchunks - 1;                                // stream padding: stay on the last slab
+      }
+    };
 #pragma unroll
     for (int j = 0; j < 8; ++j) r0.f[j] = r1.f[j] = r2.f[j] = 0.f;  // stays 0 when fmode == NONE (never loaded)
 
     auto prefetch = [&](Regs& r) {
       const int ch = cur_ch;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned off = 4u * (unsigned)((ch * 8 + j) * x_ci) + xo;
-#ifndef CMF_DBG_NOLOAD
-        r.x[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(xb) + off);
-#else
-        r.x[j] = f32x4{(float)off, 1.f, 2.f, 3.f};
-#endif
+      {
+        const int s0 = 4 * (ch * 8 + 0) * x_ci, s1 = 4 * (ch * 8 + 1) * x_ci, s2 = 4 * (ch * 8 + 2) * x_ci,
+                  s3 = 4 * (ch * 8 + 3) * x_ci, s4 = 4 * (ch * 8 + 4) * x_ci, s5 = 4 * (ch * 8 + 5) * x_ci,
+                  s6 = 4 * (ch * 8 + 6) * x_ci, s7 = 4 * (ch * 8 + 7) * x_ci;
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %8, %9, %10 offen\n\t"
+            "buffer_load_dwordx4 %1, %8, %9, %11 offen\n\t"
+            "buffer_load_dwordx4 %2, %8, %9, %12 offen\n\t"
+            "buffer_load_dwordx4 %3, %8, %9, %13 offen\n\t"
+            "buffer_load_dwordx4 %4, %8, %9, %14 offen\n\t"
+            "buffer_load_dwordx4 %5, %8, %9, %15 offen\n\t"
+            "buffer_load_dwordx4 %6, %8, %9, %16 offen\n\t"
+            "buffer_load_dwordx4 %7, %8, %9, %17 offen"
+            : "=&v"(r.x[0]), "=&v"(r.x[1]), "=&v"(r.x[2]), "=&v"(r.x[3]), "=&v"(r.x[4]), "=&v"(r.x[5]), "=&v"(r.x[6]),
+              "=&v"(r.x[7])
+            : "v"(xo), "s"(xrs), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(s6), "s"(s7)
+            : "memory");
       }
       if (has_f) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const unsigned off = 4u * (unsigned)((ch * 8 + j) * f_ci) + fo;
-          r.f[j] = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(fb) + off);
-        }
-      }
-      const unsigned wco = (unsigned)(ch * C::W_CHUNK_BYTES);
-#pragma unroll
-      for (int it = 0; it < C::NWIT; ++it) {
-        int i = lt + 256 * it;
-        i = i < C::NW_ITEMS ? i : C::NW_ITEMS - 1;
-        unsigned off;
-        if (COT == 4) {
-          off = (unsigned)i << 4;                                  // the slab is consumed whole: a linear copy
-        } else {                                                   // the global slab always has 4 co tiles per K-step
-          const int rest = i & 63, t = i >> 6;
-          const int cot = t % COT, s = (t / COT) % 3, hl = t / (3 * COT);
-          off = (unsigned)((((hl * 3 + s) * 4 + cot) * 64 + rest) << 4);
-        }
-        r.w[it] = *reinterpret_cast<const u32x4*>(wb + (wco + off));
+        const int s0 = 4 * (ch * 8 + 0) * f_ci, s1 = 4 * (ch * 8 + 1) * f_ci, s2 = 4 * (ch * 8 + 2) * f_ci,
+                  s3 = 4 * (ch * 8 + 3) * f_ci, s4 = 4 * (ch * 8 + 4) * f_ci, s5 = 4 * (ch * 8 + 5) * f_ci,
+                  s6 = 4 * (ch * 8 + 6) * f_ci, s7 = 4 * (ch * 8 + 7) * f_ci;
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dword %0, %8, %9, %10 offen\n\t"
+            "buffer_load_dword %1, %8, %9, %11 offen\n\t"
+            "buffer_load_dword %2, %8, %9, %12 offen\n\t"
+            "buffer_load_dword %3, %8, %9, %13 offen\n\t"
+            "buffer_load_dword %4, %8, %9, %14 offen\n\t"
+            "buffer_load_dword %5, %8, %9, %15 offen\n\t"
+            "buffer_load_dword %6, %8, %9, %16 offen\n\t"
+            "buffer_load_dword %7, %8, %9, %17 offen"
+            : "=&v"(r.f[0]), "=&v"(r.f[1]), "=&v"(r.f[2]), "=&v"(r.f[3]), "=&v"(r.f[4]), "=&v"(r.f[5]), "=&v"(r.f[6]),
+              "=&v"(r.f[7])
+            : "v"(fo), "s"(frs), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(s6), "s"(s7)
+            : "memory");
       }
       r.okf = okf;
       if (++cur_ch == nchunks) {                                   // advance the cursor (wave-uniform)
         cur_ch = 0;
-        if (++cur_item < n_items) set_item(cur_item);
+        if (cur_item + 1 < n_items) set_item(++cur_item);
+        else cur_ch = nchunks - 1;                                 // stream padding: stay on the last chunk
       }
+    };
+    // hand-counted waits; the "+v" operands make every consumer of the set depend on the wait statement
+    constexpr int NW = C::NWIT;
+    auto wait_x = [&](Regs& r) {                                   // X,f of `r` landed; W, X,f, W, X,f may still fly
+      if constexpr (has_f)
+        asm volatile("s_waitcnt vmcnt(%16)"
+                     : "+v"(r.x[0]), "+v"(r.x[1]), "+v"(r.x[2]), "+v"(r.x[3]), "+v"(r.x[4]), "+v"(r.x[5]), "+v"(r.x[6]),
+                       "+v"(r.x[7]), "+v"(r.f[0]), "+v"(r.f[1]), "+v"(r.f[2]), "+v"(r.f[3]), "+v"(r.f[4]), "+v"(r.f[5]),
+                       "+v"(r.f[6]), "+v"(r.f[7])
+                     : "n"(2 * NW + 32));
+      else
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(r.x[0]), "+v"(r.x[1]), "+v"(r.x[2]), "+v"(r.x[3]), "+v"(r.x[4]), "+v"(r.x[5]), "+v"(r.x[6]),
+                       "+v"(r.x[7])
+                     : "n"(2 * NW + 16));
+    };
+    auto wait_w = [&]() {                                          // the slab landed; the newest X,f may still fly
+      static_assert(C::NWIT == 6 || C::NWIT == 3, "operand list below");
+      constexpr int N = has_f ? 16 : 8;
+      if constexpr (C::NWIT == 6)
+        asm volatile("s_waitcnt vmcnt(%6)"
+                     : "+v"(wreg[0]), "+v"(wreg[1]), "+v"(wreg[2]), "+v"(wreg[3]), "+v"(wreg[4]), "+v"(wreg[5])
+                     : "n"(N));
+      else
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wreg[0]), "+v"(wreg[1]), "+v"(wreg[2]) : "n"(N));
     };
 
     auto commit = [&](Regs& r, int stage) {
@@ -228,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
       for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(r.x[j]), "v"(r.f[j]));
 #pragma unroll
-      for (int it = 0; it < C::NWIT; ++it) asm volatile("" ::"v"(r.w[it]));
+      for (int it = 0; it < C::NWIT; ++it) asm volatile("" ::"v"(wreg[it]));
       return;
 #endif
       unsigned char* Xh = smem + stage * C::BUF_BYTES;
@@ -236,28 +326,47 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       unsigned char* Wh = Xh + 2 * C::XS_BYTES;
       unsigned char* Wl = Wh + C::WS_BYTES;
       if (lt < C::NX_ITEMS) {
-        float v[8][4];
+        // Values are paired ALONG THE COLUMNS (the two halves of a loaded float4 are already register pairs), so the
+        // scale and the remainder are v_pk_* ops without the v_mov pairs a channel pairing needed; v_cvt_pk_bf16_f32
+        // takes any two registers, so the (channel 2jj, 2jj+1) packing is free.  ~3 VALU per element.
+        f32x2 v[8][2];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float f = r.f[j];
           const float m = r.okf * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[j][c] = (SELF ? fmaxf(r.x[j][c], 0.f) : r.x[j][c]) * m;
+          f32x2 lo2 = f32x2{r.x[j][0], r.x[j][1]}, hi2 = f32x2{r.x[j][2], r.x[j][3]};
+          if (SELF) {
+            lo2 = f32x2{fmaxf(lo2[0], 0.f), fmaxf(lo2[1], 0.f)};
+            hi2 = f32x2{fmaxf(hi2[0], 0.f), fmaxf(hi2[1], 0.f)};
+          }
+          v[j][0] = lo2 * m;
+          v[j][1] = hi2 * m;
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {                              // column q*4 + c: 8 channels -> 16 B hi + 16 B lo
-          u32x4 h, l;
+        for (int cp = 0; cp < 2; ++cp) {                           // columns q*4 + 2cp, q*4 + 2cp + 1
+          u32x4 hA, lA, hB, lB;
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
-            float e0, e1;
-            h[jj] = pack_hi(v[2 * jj][c], v[2 * jj + 1][c], e0, e1);
-            l[jj] = pack_lo(e0, e1);
+            const f32x2 e = v[2 * jj][cp], o = v[2 * jj + 1][cp];  // even / odd channel of the pair
+            const unsigned a_ = pack_lo(e[0], o[0]), b_ = pack_lo(e[1], o[1]);
+            const f32x2 he = f32x2{__builtin_bit_cast(float, a_ << 16), __builtin_bit_cast(float, b_ << 16)};
+            const f32x2 ho = f32x2{__builtin_bit_cast(float, a_ & 0xffff0000u), __builtin_bit_cast(float, b_ & 0xffff0000u)};
+            const f32x2 re = e - he, ro = o - ho;
+            hA[jj] = a_;
+            hB[jj] = b_;
+            lA[jj] = pack_lo(re[0], ro[0]);
+            lB[jj] = pack_lo(re[1], ro[1]);
           }
-          const int off = ((pix * 16 + xslot(q * 4 + c, pix)) << 4);
-          *reinterpret_cast<u32x4*>(Xh + off) = h;
-          *reinterpret_cast<u32x4*>(Xl + off) = l;
+          const int offA = ((pix * 16 + xslot(q * 4 + 2 * cp, pix)) << 4);
+          const int offB = ((pix * 16 + xslot(q * 4 + 2 * cp + 1, pix)) << 4);
+          *reinterpret_cast<u32x4*>(Xh + offA) = hA;
+          *reinterpret_cast<u32x4*>(Xl + offA) = lA;
+          *reinterpret_cast<u32x4*>(Xh + offB) = hB;
+          *reinterpret_cast<u32x4*>(Xl + offB) = lB;
+          __builtin_amdgcn_sched_barrier(0);                       // keep the two halves apart: bounds the live temporaries
         }
       }
+      wait_w();
 #pragma unroll
       for (int it = 0; it < C::NWIT; ++it) {
         const int i = lt + 256 * it;
@@ -265,28 +374,35 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
           const int rest = i & 63, t = i >> 6;
           const int cot = t % COT, s = (t / COT) % 3, hl = t / (3 * COT);
           unsigned char* dst = (hl ? Wl : Wh) + ((((s * COT + cot) * 64) + rest) << 4);
-          *reinterpret_cast<u32x4*>(dst) = r.w[it];
+          *reinterpret_cast<u32x4*>(dst) = wreg[it];
         }
       }
     };
 
-    if (n_items > 0) set_item(0);
-    if (total_chunks > 0) prefetch(r0);
-    if (total_chunks > 1) prefetch(r1);
-    if (total_chunks > 2) prefetch(r2);
-    if (total_chunks > 0) commit(r0, 0);
+    if (n_items > 0) {
+      set_item(0);
+      wset_item(0);
+      prefetch(r0);                                                // chunks 0, 1, 2 (padded past the end of the stream)
+      prefetch(r1);
+      prefetch(r2);
+      prefetch_w();                                                // slab 0
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_x(r0);
+      commit(r0, 0);
+      prefetch_w();                                                // slab 1
+    }
     __syncthreads();                                               // stage 0 ready
     // iteration g: the MFMA waves consume stage g&1 (stream chunk g); set g%3 is free -> stream chunk g+3;
     // stage (g+1)&1 <- chunk g+1 from set (g+1)%3.  Exactly one barrier per iteration, matching the MFMA waves.
+    // Every iteration issues the same loads in the same order (see the wait counts above).
     auto iter = [&](int g, Regs& freed, Regs& next) {
       STAMP(1, g, 0);
-      if (g + 3 < total_chunks) prefetch(freed);
+      prefetch(freed);
       STAMP(1, g, 1);
-#ifdef CMF_DBG_STAMP
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 8 + C::NWIT));   // the loads of `next` have landed (this set's may fly)
+      wait_x(next);
       STAMP(1, g, 2);
-#endif
-      if (g + 1 < total_chunks) commit(next, (g + 1) & 1);
+      commit(next, (g + 1) & 1);
+      prefetch_w();                                                // slab of chunk g + 2 into the registers just written out
       STAMP(1, g, 3);
       __syncthreads();
     };
@@ -297,6 +413,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       if (g + 2 >= total_chunks) break;
       iter(g + 2, r2, r0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // padding loads still in flight
     return;
   }
 
@@ -323,56 +440,87 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // set.  Everything is unrolled, so ring slots are static registers and hipcc emits counted lgkmcnt waits.
   constexpr int BD = 4, NSTEP = 3 * PW;
 
-  // Item context: output / residual bases and validity of this wave's tile row.
+  // Item context.  The launcher guarantees whole tiles (H even, W % TW == 0) and whole channel groups, so the tail has
+  // NO per-pixel / per-channel validity tests, and every access is a raw buffer op: descriptor base = the item's
+  // wave-uniform base, voffset = the lane's fixed byte offset, soffset = pixel / channel-tile term (SALU).  A missing
+  // residual (or "no next item") is a descriptor with zero records: its loads return 0 without touching memory, so
+  // the tail is branch-free.  (Before: ~70 instructions and 5-6 branches per pixel, 64-bit address arithmetic,
+  // v_mul_lo -- the tail cost ~18k cycles per item, as much as three chunks.)
+  typedef unsigned bu32x4 __attribute__((vector_size(16)));        // the type the raw buffer builtins use
+  constexpr int RS_FLAGS = 0x00020000;
+  const int yvoff = 4 * ((cohalf * CW * 16 + cl) * y_co + kq * 4); // lane (kq, cl): columns kq*4..+3 of channel cl (+16c)
+  const int rvoff = 4 * ((cohalf * CW * 16 + cl) * r_co + kq * 4);
   struct Item {
-    float* y;
-    const float* r;
-    int y0, x0, co0;
-    bool full;
+    int ypix, rpix;                                                // byte offset of pixel p = 0 of this wave's tile row
+    float bias[CW];                                                // this lane's per-channel constants, fetched ONCE per item
   };
-  auto make_item = [&](int item) {
-    int tile, slice, cog, np;
+  auto item_geom = [&](int item, int& np, int& slice, int& cog, Item& it) {
+    int tile;
     decode(item, tile, slice, cog, np);
-    Item it;
-    it.y0 = 2 * (tile / tiles_x);
-    it.x0 = C::TW * (tile % tiles_x);
-    // lane (kq, cl) owns columns slice*16 + kq*4 .. +3 of output channel co0 + c*16
-    it.y = a.y + (long long)np * a.y_np + slice * 16 + kq * 4;
-    it.r = a.r ? a.r + (long long)np * a.r_np + slice * 16 + kq * 4 : nullptr;
-    it.co0 = cog * 64 + cohalf * CW * 16 + cl;
-    it.full = (cog * 64 + COT * 16) <= a.cout;
-    return it;
+    const int pix0 = (2 * (tile / tiles_x) + wrow) * a.W + C::TW * (tile % tiles_x);
+    it.ypix = 4 * pix0 * y_px;
+    it.rpix = 4 * pix0 * r_px;
+    // (a per-store `a.bias ? a.bias[..] : 0` put a dependent load + s_waitcnt vmcnt(0) in front of EVERY store: each
+    // pixel of the tail then drained all outstanding stores and residual loads -- ~28k cycles per item)
+#pragma unroll
+    for (int c = 0; c < CW; ++c) it.bias[c] = a.bias ? a.bias[cog * 64 + cohalf * CW * 16 + cl + c * 16] : 0.f;
+  };
+  // descriptors are built from readfirstlane'd words: hipcc otherwise keeps the loop-carried residual descriptor in
+  // VGPRs and wraps every load in a waterfall loop
+  auto uniform_rsrc = [&](const float* p, int records) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(records), RS_FLAGS);
+  };
+  auto y_rsrc = [&](int np, int slice, int cog) {
+    return uniform_rsrc(a.y + (long long)np * a.y_np + slice * 16 + (long long)cog * 64 * y_co, -1);
+  };
+  auto r_rsrc = [&](int np, int slice, int cog, bool on) {
+    const float* base = a.r ? a.r + (long long)np * a.r_np + slice * 16 + (long long)cog * 64 * r_co : a.y;
+    return uniform_rsrc(base, (a.r && on) ? -1 : 0);
   };
   f32x4 acc[PW][CW];
-  // accumulator initial value of pixel p = residual (or zero)
-  auto init_pixel = [&](const Item& it, int p) {
-    const int gy = it.y0 + wrow, gx = it.x0 + p;
+  Item cur, nxt;
+  int np_, slice_, cog_;
+  item_geom(0, np_, slice_, cog_, cur);
+  nxt = cur;
+  auto cur_yrs = y_rsrc(np_, slice_, cog_);
+  auto cur_rrs = r_rsrc(np_, slice_, cog_, n_items > 0);
+  auto nxt_rrs = cur_rrs;
+  // accumulator initial value of pixel p = residual (zero-record descriptor: zeros); straight into the accumulators
+  auto init_pixel = [&](const Item& it, decltype(cur_rrs) rrs, int p) {
 #pragma unroll
-    for (int c = 0; c < CW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (it.r && gy < a.H && gx < a.W) {                 // loads go straight into the accumulators (no temporaries)
-      const float* rp = it.r + (gy * a.W + gx) * r_px + it.co0 * r_co;
-#pragma unroll
-      for (int c = 0; c < CW; ++c)
-        if (it.full || (it.co0 + c * 16) < a.cout) acc[p][c] = *reinterpret_cast<const f32x4*>(rp + (c * 16) * r_co);
+    for (int c = 0; c < CW; ++c) {
+      const bu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rrs, rvoff, it.rpix + 4 * (p * r_px + c * 16 * r_co), 0);
+      acc[p][c] = __builtin_bit_cast(f32x4, t);
     }
   };
   auto store_pixel = [&](const Item& it, int p) {
-    const int gy = it.y0 + wrow, gx = it.x0 + p;
-    if (!(gy < a.H && gx < a.W)) return;
-    float* yp = it.y + (gy * a.W + gx) * y_px + it.co0 * y_co;
 #pragma unroll
-    for (int c = 0; c < CW; ++c)
-      if (it.full || (it.co0 + c * 16) < a.cout) {
-        const float bv = a.bias ? a.bias[it.co0 + c * 16] : 0.f;     // per-channel constant (primal bias), added at store
-        *reinterpret_cast<f32x4*>(yp + (c * 16) * y_co) = acc[p][c] + bv;
-      }
+    for (int c = 0; c < CW; ++c) {
+      const f32x4 v = acc[p][c] + it.bias[c];                      // per-channel constant (primal bias)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, v), cur_yrs, yvoff,
+                                             it.ypix + 4 * (p * y_px + c * 16 * y_co), 0);
+    }
   };
 
   // One 8-channel chunk from LDS stage `stage`.  LAST = the item's final chunk: pixel p's accumulators are final
   // after its K-step-2 MFMAs, so its 16-byte stores are issued right there and the NEXT item's residual loads go
   // straight into the freed registers -- the VMEM issue cost of the tail (measured ~335 cycles per store / load
   // instruction, ~9.4k + ~9k cycles per item when done as a block) hides under the remaining MFMAs.
-  auto chunk = [&](int stage, auto LAST, const Item& cur, const Item& nxt, bool has_next) {
+  auto chunk = [&](int stage, auto LAST) {
+#ifdef CMF_DBG_NOMFMA
+    if (LAST) {                                    // timing-only build: the MFMA waves only run the tail and the barriers
+#pragma unroll
+      for (int p = 0; p < PW; ++p) {
+        store_pixel(cur, p);
+        init_pixel(nxt, nxt_rrs, p);
+      }
+    }
+    return;
+#endif
     const unsigned char* Xh = smem + stage * C::BUF_BYTES;
     const unsigned char* Xl = Xh + C::XS_BYTES;
     const unsigned char* Wh = Xh + 2 * C::XS_BYTES;
@@ -409,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       }
       if (LAST && s == 2) {
         store_pixel(cur, p);
-        if (has_next) init_pixel(nxt, p);
+        init_pixel(nxt, nxt_rrs, p);
       }
       // keep this step's reads-then-MFMAs(-then-tail) order: without the fence hipcc's scheduler re-clusters the
       // ds_reads next to their uses (lgkmcnt(0) before most MFMA groups) and the ring no longer hides LDS latency
@@ -418,23 +566,29 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   };
 
   int g = 0;                                                       // stream chunk index -> LDS stage g & 1
-  Item cur = make_item(0), nxt = cur;
-  if (n_items > 0) {
 #pragma unroll
-    for (int p = 0; p < PW; ++p) init_pixel(cur, p);
-  }
+  for (int p = 0; p < PW; ++p) init_pixel(cur, cur_rrs, p);
   __syncthreads();                                                 // stage 0 ready
   for (int item = 0; item < n_items; ++item) {
     const bool has_next = item + 1 < n_items;
-    if (has_next) nxt = make_item(item + 1);
     for (int ch = 0; ch < nchunks - 1; ++ch, ++g) {
-      chunk(g & 1, std::false_type{}, cur, nxt, has_next);
+      chunk(g & 1, std::false_type{});
       __syncthreads();                                             // stage (g+1)&1 ready, stage g&1 free
     }
-    chunk(g & 1, std::true_type{}, cur, nxt, has_next);
+    // the next item's context is derived right before the chunk that uses it (carried across the chunk loop the
+    // descriptors ended up in VGPRs + waterfall loops)
+    auto nxt_yrs = cur_yrs;
+    {
+      int np, slice, cog;
+      item_geom(has_next ? item + 1 : item, np, slice, cog, nxt);
+      nxt_yrs = y_rsrc(np, slice, cog);
+      nxt_rrs = r_rsrc(np, slice, cog, has_next);                  // last item: zero records, nothing is fetched
+    }
+    chunk(g & 1, std::true_type{});
     __syncthreads();
     ++g;
     cur = nxt;
+    cur_yrs = nxt_yrs;
   }
 }
 
@@ -478,7 +632,10 @@ int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
       cus = 256;
     n_cu = cus > 0 ? cus : 256;
   }
-  const int grid = (int)(total < n_cu ? total : n_cu);          // persistent: one 112 KiB workgroup per CU
+  int grid = (int)(total < n_cu ? total : n_cu);                // persistent: one 112 KiB workgroup per CU
+#ifdef CMF_DBG_STAMP
+  if (const char* e = getenv("CMF_DBG_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;   // diagnostic: fewer active CUs
+#endif
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles, nslices, ncog, (int)total);
   CMF_LAUNCH_CHECK();
   return 0;
@@ -511,8 +668,9 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   const cmf_conv_tangent_args& a = *ap;
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
   if (a.taps != 9 || a.cin % 8 || a.nc <= 0 || a.nc % 16) return CMF_EINVAL;
-  if (a.fmode < CMF_F_NONE || a.fmode > CMF_F_SELF_RELU) return CMF_EINVAL;
-  if (a.fmode != CMF_F_NONE && a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
+  if (a.fmode <= CMF_F_NONE || a.fmode > CMF_F_SELF_RELU) return CMF_EINVAL;   // NONE: use cmf_conv_tangent (the loader's
+                                                                              // load schedule always carries a factor stream)
+  if (a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
   if ((a.x_np | a.x_ci | a.x_px) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
   if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;            // 16-byte stores
   if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;    // 16-byte residual loads
@@ -522,6 +680,8 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
       HW > (1 << 24))
     return CMF_ERANGE;
   hipStream_t s = (hipStream_t)stream;
-  if (a.W % 14) return CMF_EINVAL;      // only the 7-pixel-per-wave tiling is built (14- and 28-wide images)
+  // only the 7-pixel-per-wave tiling is built (14- and 28-wide images); the kernel has no partial-tile / partial-channel-
+  // group code: whole 2 x 14 tiles and whole groups of 64 (or exactly 32) output channels only
+  if (a.W % 14 || a.H % 2 || !(a.cout % 64 == 0 || a.cout == 32)) return CMF_EINVAL;
   return launch_cot<7>(a, s);
 }

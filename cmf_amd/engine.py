@@ -77,8 +77,10 @@ TIMER = None   # set to a KernelTimer by bench.py
 TANGENT_PRECISION = "bf16x3"
 
 
-def _use_bf16x3(taps, cin, W, transpose):
-    return TANGENT_PRECISION == "bf16x3" and taps == 9 and cin % 8 == 0 and W % 14 == 0 and not transpose
+def _use_bf16x3(taps, cin, W, transpose, H=None, cout=64):
+    """Shapes the split-precision kernel is built for: whole 2 x 14 pixel tiles, whole 64- (or one 32-) channel groups."""
+    return (TANGENT_PRECISION == "bf16x3" and taps == 9 and cin % 8 == 0 and W % 14 == 0 and (H is None or H % 2 == 0)
+            and (cout % 64 == 0 or cout == 32) and not transpose)
 
 
 class Tangent:
@@ -176,7 +178,7 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     a = ConvTangentArgs()
     a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
     a.f = _p(f); a.f_np, a.f_ci, a.f_px = int(f_np), int(f_ci), int(f_px); a.fmode = fmode
-    split = _use_bf16x3(taps, cin, W, transpose)
+    split = _use_bf16x3(taps, cin, W, transpose, H, cout) and fmode != F_NONE      # the split kernel always streams a factor
     a.w = _p(PACKS.get(weight, taps, transpose, bf16x3=split))
     a.y = _p(y_t); a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
     a.r = _p(res_t); a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
@@ -373,7 +375,7 @@ def net_primal(net, z, view, need_acts=True):
         a = new(hid)
         conv_primal(z, view.chan_off * HW, geo.C * HW, view.chan_step * HW, 1, conv0.weight, 9, None, a, hid * HW, HW, 1,
                     B, view.cin, hid, H, W, imode=F_RAW if view.mask is not None else F_NONE, mask=view.mask, f_c=HW, f_px=1)
-        if B % 16 == 0 and _use_bf16x3(9, hid, W, False):
+        if B % 16 == 0 and _use_bf16x3(9, hid, W, False, H, hid):
             return _resnet_primal_grouped(net, blocks, convf, a, B, hid, cout, H, W, need_acts)
         acts = [a]
         for blk in blocks:

@@ -76,10 +76,12 @@ typedef struct {
 } cmf_conv_tangent_args;
 int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
 
-/* Split-precision variant of cmf_conv_tangent for taps == 9, cin % 8 == 0, W % 14 == 0: operands are split
+/* Split-precision variant of cmf_conv_tangent for taps == 9, cin % 8 == 0, W % 14 == 0, H % 2 == 0 and
+ * cout % 64 == 0 or cout == 32 (anything else: CMF_EINVAL, use cmf_conv_tangent): operands are split
  * v = hi + lo (bf16 each) and multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
  * accumulation (fp32-grade result, ~2^-16 relative per product).  `w` must come from
- * cmf_pack_weight_bf16x3 (out == NULL: size query in bytes through *out_bytes).                     */
+ * cmf_pack_weight_bf16x3 (out == NULL: size query in bytes through *out_bytes).  fmode CMF_F_NONE is
+ * rejected (CMF_EINVAL): this kernel's load schedule always carries a factor stream; use cmf_conv_tangent. */
 int cmf_pack_weight_bf16x3(const float* w, void* out, int cout, int cin, long long* out_bytes, void* stream);
 int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* a, void* stream);
 

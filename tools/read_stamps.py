@@ -4,7 +4,7 @@ import ctypes as C, os, sys, subprocess
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from cmf_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "cmf_amd/csrc/_obj/dbg_STAMP.so")
+_lib.LIB_PATH = os.path.join(ROOT, "cmf_amd/csrc/_obj", os.environ.get("CMF_DBG_LIB", "dbg_STAMP.so"))
 from cmf_amd import engine as E
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 B, H, nc, ch = 128, 28, 64, 64; HW = H * H
