@@ -24,7 +24,7 @@ class ConvTangentArgs(C.Structure):
                 ("y", _fp), ("y_np", _ll), ("y_co", _ll), ("y_px", _ll),
                 ("r", _fp), ("r_np", _ll), ("r_co", _ll), ("r_px", _ll),
                 ("np", _i), ("cin", _i), ("cout", _i), ("H", _i), ("W", _i), ("nc", _i), ("taps", _i),
-                ("bias", _fp), ("f_group", _i)]
+                ("bias", _fp), ("f_group", _i), ("x_sl", _ll), ("y_sl", _ll), ("r_sl", _ll)]
 
 
 class ConvPrimalArgs(C.Structure):

@@ -20,6 +20,10 @@ LIB = os.path.join(HERE, "libcmf_amd.so")
 ARCH = "gfx950"
 
 
+# conv_tangent_bf16x3: no SLP packing of f32 pairs into v_pk_*_f32 in the loader waves (slower beside MFMAs)
+PER_FILE_FLAGS = {"conv_tangent_bf16x3.hip": ["-fno-slp-vectorize"]}
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if cand and os.path.exists(cand):
@@ -49,7 +53,8 @@ def build(force=False, verbose=True):
 
     def one(src):
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-        r = subprocess.run([cc, *flags, "-c", src, "-o", obj], capture_output=True, text=True)
+        extra = PER_FILE_FLAGS.get(os.path.basename(src), [])
+        r = subprocess.run([cc, *flags, *extra, "-c", src, "-o", obj], capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
         return obj

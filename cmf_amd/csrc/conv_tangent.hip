@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
     p0 = tile * 4 * PXW;
   }
 
-  const float* xb = a.x + (long long)np * a.x_np + slice * 16;
+  const float* xb = a.x + (long long)np * a.x_np + (long long)slice * (a.x_sl ? a.x_sl : 16);
   const int fgrp = a.f_group > 1 ? a.f_group : 1;
   const float* fb = a.f ? a.f + (long long)(np / fgrp) * a.f_np + (np % fgrp) : nullptr;
   const float* wb = a.w + (long long)cog * TAPS * cin_pad * 64;  // one co-group slab: < 2^31 floats
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
 
   // ---- epilogue: D[row = kq*4 + r][col = cl] of tile (p, c); offsets fit 32 bits (host-checked) ----
   const int y_co = (int)a.y_co, y_px = (int)a.y_px, r_co = (int)a.r_co, r_px = (int)a.r_px;
-  float* ybase = a.y + (long long)np * a.y_np + slice * 16 + cl;
-  const float* rbase = a.r ? a.r + (long long)np * a.r_np + slice * 16 + cl : nullptr;
+  float* ybase = a.y + (long long)np * a.y_np + (long long)slice * (a.y_sl ? a.y_sl : 16) + cl;
+  const float* rbase = a.r ? a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) + cl : nullptr;
   const int co0 = cog * 64 + kq * 4;
   const bool full = (cog * 64 + COT * 16) <= a.cout;   // uniform: no per-channel bound checks needed
 
@@ -330,7 +330,7 @@ extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
   if (a.fmode < CMF_F_NONE || a.fmode > CMF_F_SELF_RELU) return CMF_EINVAL;
   if (a.fmode != CMF_F_NONE && a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
   // 16-byte vector loads of the column slices
-  if ((a.x_np | a.x_ci | a.x_px) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
+  if ((a.x_np | a.x_ci | a.x_px | a.x_sl | a.y_sl | a.r_sl) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
   const long long HW = (long long)a.H * a.W;
   // per-sample offsets are held in 32-bit registers
   if (!fits_int((a.cin + 8) * a.x_ci + HW * a.x_px + a.nc) || !fits_int((a.cin + 8) * a.f_ci + HW * a.f_px) ||

@@ -136,7 +136,9 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     // Measured with in-kernel stamps: a loader's ~220 VALU + 14 ds_write per chunk took ~4000 cycles beside an MFMA
     // wave on the same SIMD and set the chunk period.  VALU issue is arbitrated by priority, then age: raise the
     // loaders (an MFMA wave needs one issue slot per 16 cycles and barely notices).
+#ifndef CMF_DBG_NOPRIO
     __builtin_amdgcn_s_setprio(3);
+#endif
     const int lt = tid - 256;                                    // 0..255: staging item = (pixel, column quad)
     const int x_ci = (int)a.x_ci, x_px = (int)a.x_px, f_ci = (int)a.f_ci, f_px = (int)a.f_px;
     const int q = lt & 3, pix = lt >> 2;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       int tile, slice, cog, np;
       decode(item, tile, slice, cog, np);
       const int y0 = 2 * (tile / tiles_x), x0 = C::TW * (tile % tiles_x);
-      xrs = make_rsrc(a.x + (long long)np * a.x_np + slice * 16);
+      xrs = make_rsrc(a.x + (long long)np * a.x_np + (long long)slice * (a.x_sl ? a.x_sl : 16));
       frs = make_rsrc(a.f ? a.f + (long long)(np / fgrp) * a.f_np + (np % fgrp) : a.x);
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
       const bool ok = lt < C::NX_ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
@@ -329,41 +331,32 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         // Values are paired ALONG THE COLUMNS (the two halves of a loaded float4 are already register pairs), so the
         // scale and the remainder are v_pk_* ops without the v_mov pairs a channel pairing needed; v_cvt_pk_bf16_f32
         // takes any two registers, so the (channel 2jj, 2jj+1) packing is free.  ~3 VALU per element.
-        f32x2 v[8][2];
+        // SCALAR f32 multiplies / subtractions on purpose (and -fno-slp-vectorize for this file): beside a saturating
+        // MFMA wave a v_pk_mul/fma_f32 costs ~20 cycles more than the two scalar ops it replaces.
+        float v[8][4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float f = r.f[j];
           const float m = r.okf * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
-          f32x2 lo2 = f32x2{r.x[j][0], r.x[j][1]}, hi2 = f32x2{r.x[j][2], r.x[j][3]};
-          if (SELF) {
-            lo2 = f32x2{fmaxf(lo2[0], 0.f), fmaxf(lo2[1], 0.f)};
-            hi2 = f32x2{fmaxf(hi2[0], 0.f), fmaxf(hi2[1], 0.f)};
-          }
-          v[j][0] = lo2 * m;
-          v[j][1] = hi2 * m;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[j][c] = (SELF ? fmaxf(r.x[j][c], 0.f) : r.x[j][c]) * m;
         }
 #pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {                           // columns q*4 + 2cp, q*4 + 2cp + 1
-          u32x4 hA, lA, hB, lB;
+        for (int c = 0; c < 4; ++c) {                              // column q*4 + c: 8 channels -> 16 B hi + 16 B lo
+          u32x4 h, l;
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
-            const f32x2 e = v[2 * jj][cp], o = v[2 * jj + 1][cp];  // even / odd channel of the pair
-            const unsigned a_ = pack_lo(e[0], o[0]), b_ = pack_lo(e[1], o[1]);
-            const f32x2 he = f32x2{__builtin_bit_cast(float, a_ << 16), __builtin_bit_cast(float, b_ << 16)};
-            const f32x2 ho = f32x2{__builtin_bit_cast(float, a_ & 0xffff0000u), __builtin_bit_cast(float, b_ & 0xffff0000u)};
-            const f32x2 re = e - he, ro = o - ho;
-            hA[jj] = a_;
-            hB[jj] = b_;
-            lA[jj] = pack_lo(re[0], ro[0]);
-            lB[jj] = pack_lo(re[1], ro[1]);
+            const float e = v[2 * jj][c], o = v[2 * jj + 1][c];    // even / odd channel of the pair
+            const unsigned hb = pack_lo(e, o);                     // v_cvt_pk_bf16_f32 (RNE)
+            const float re = e - __builtin_bit_cast(float, hb << 16);
+            const float ro = o - __builtin_bit_cast(float, hb & 0xffff0000u);
+            h[jj] = hb;
+            l[jj] = pack_lo(re, ro);
           }
-          const int offA = ((pix * 16 + xslot(q * 4 + 2 * cp, pix)) << 4);
-          const int offB = ((pix * 16 + xslot(q * 4 + 2 * cp + 1, pix)) << 4);
-          *reinterpret_cast<u32x4*>(Xh + offA) = hA;
-          *reinterpret_cast<u32x4*>(Xl + offA) = lA;
-          *reinterpret_cast<u32x4*>(Xh + offB) = hB;
-          *reinterpret_cast<u32x4*>(Xl + offB) = lB;
-          __builtin_amdgcn_sched_barrier(0);                       // keep the two halves apart: bounds the live temporaries
+          const int off = ((pix * 16 + xslot(q * 4 + c, pix)) << 4);
+          *reinterpret_cast<u32x4*>(Xh + off) = h;
+          *reinterpret_cast<u32x4*>(Xl + off) = l;
+          if (c == 1) __builtin_amdgcn_sched_barrier(0);           // bounds the live temporaries
         }
       }
       wait_w();
@@ -418,6 +411,9 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   }
 
   // ================================= MFMA waves =================================
+#ifdef CMF_DBG_MFMAPRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
   const int wrow = wave >> 1, cohalf = wave & 1;
   const int y_co = (int)a.y_co, y_px = (int)a.y_px, r_co = (int)a.r_co, r_px = (int)a.r_px;
 
@@ -438,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // Fragment pipeline: step t = s*PW + p consumes B fragment pair t; pairs are fetched BD-1 steps ahead into a ring
   // of BD register pairs, the A fragments of K-step s+1 are fetched at the start of K-step s into the alternate
   // set.  Everything is unrolled, so ring slots are static registers and hipcc emits counted lgkmcnt waits.
-  constexpr int BD = 4, NSTEP = 3 * PW;
+  constexpr int BD = 4, NSTEP = 3 * PW;                            // step t = 3*p + s (pixel-major)
 
   // Item context.  The launcher guarantees whole tiles (H even, W % TW == 0) and whole channel groups, so the tail has
   // NO per-pixel / per-channel validity tests, and every access is a raw buffer op: descriptor base = the item's
@@ -452,7 +448,6 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   const int rvoff = 4 * ((cohalf * CW * 16 + cl) * r_co + kq * 4);
   struct Item {
     int ypix, rpix;                                                // byte offset of pixel p = 0 of this wave's tile row
-    float bias[CW];                                                // this lane's per-channel constants, fetched ONCE per item
   };
   auto item_geom = [&](int item, int& np, int& slice, int& cog, Item& it) {
     int tile;
@@ -460,57 +455,94 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     const int pix0 = (2 * (tile / tiles_x) + wrow) * a.W + C::TW * (tile % tiles_x);
     it.ypix = 4 * pix0 * y_px;
     it.rpix = 4 * pix0 * r_px;
-    // (a per-store `a.bias ? a.bias[..] : 0` put a dependent load + s_waitcnt vmcnt(0) in front of EVERY store: each
-    // pixel of the tail then drained all outstanding stores and residual loads -- ~28k cycles per item)
-#pragma unroll
-    for (int c = 0; c < CW; ++c) it.bias[c] = a.bias ? a.bias[cog * 64 + cohalf * CW * 16 + cl + c * 16] : 0.f;
   };
-  // descriptors are built from readfirstlane'd words: hipcc otherwise keeps the loop-carried residual descriptor in
-  // VGPRs and wraps every load in a waterfall loop
-  auto uniform_rsrc = [&](const float* p, int records) {
-    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  // descriptors are built from readfirstlane'd words: hipcc otherwise keeps loop-carried descriptors in VGPRs and
+  // wraps every access in a waterfall loop
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  auto y_rsrc = [&](int np, int slice, int cog) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(a.y + (long long)np * a.y_np + (long long)slice * (a.y_sl ? a.y_sl : 16) + (long long)cog * 64 * y_co);
     const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
     const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0,
-                                             __builtin_amdgcn_readfirstlane(records), RS_FLAGS);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, -1, RS_FLAGS);
   };
-  auto y_rsrc = [&](int np, int slice, int cog) {
-    return uniform_rsrc(a.y + (long long)np * a.y_np + slice * 16 + (long long)cog * 64 * y_co, -1);
-  };
-  auto r_rsrc = [&](int np, int slice, int cog, bool on) {
-    const float* base = a.r ? a.r + (long long)np * a.r_np + slice * 16 + (long long)cog * 64 * r_co : a.y;
-    return uniform_rsrc(base, (a.r && on) ? -1 : 0);
+  auto r_rsrc = [&](int np, int slice, int cog, bool on) {         // words, for the inline-asm loads
+    const float* base = a.r ? a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) + (long long)cog * 64 * r_co : a.y;
+    const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+    i32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    d[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(u >> 32) & 0xffffu));
+    d[2] = __builtin_amdgcn_readfirstlane((a.r && on) ? -1 : 0);   // zero records: loads return 0, nothing is fetched
+    d[3] = RS_FLAGS;
+    return d;
   };
   f32x4 acc[PW][CW];
   Item cur, nxt;
   int np_, slice_, cog_;
   item_geom(0, np_, slice_, cog_, cur);
   nxt = cur;
-  auto cur_yrs = y_rsrc(np_, slice_, cog_);
-  auto cur_rrs = r_rsrc(np_, slice_, cog_, n_items > 0);
-  auto nxt_rrs = cur_rrs;
-  // accumulator initial value of pixel p = residual (zero-record descriptor: zeros); straight into the accumulators
-  auto init_pixel = [&](const Item& it, decltype(cur_rrs) rrs, int p) {
+  // Per-channel constants (primal bias): a bias implies a single channel group (launcher precondition), so they are
+  // fetched ONCE per launch -- by inline asm like the residual, so that hipcc never places a vmcnt wait of its own
+  // among the hand-counted ones; a NULL bias is a zero-record descriptor (reads 0).  (A per-store
+  // `a.bias ? a.bias[..] : 0` once put a dependent load + s_waitcnt vmcnt(0) in front of EVERY store: ~28k cycles/item.)
+  float bias[CW];
+  {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(a.bias ? a.bias : a.y);
+    i32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    d[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(u >> 32) & 0xffffu));
+    d[2] = __builtin_amdgcn_readfirstlane(a.bias ? -1 : 0);
+    d[3] = RS_FLAGS;
+    const int bvo = 4 * (cohalf * CW * 16 + cl);
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-      const bu32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rrs, rvoff, it.rpix + 4 * (p * r_px + c * 16 * r_co), 0);
-      acc[p][c] = __builtin_bit_cast(f32x4, t);
+      const int so = 4 * c * 16;
+      asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(bias[c]) : "v"(bvo), "s"(d), "s"(so) : "memory");
+    }
+  }
+  auto cur_yrs = y_rsrc(np_, slice_, cog_);
+  i32x4 nxt_rrs = r_rsrc(np_, slice_, cog_, n_items > 0);
+  // Accumulator initial value of pixel p = residual, loaded straight into the accumulators by INLINE ASM with
+  // hand-counted waits (wait_res below): hipcc's vmcnt for these loads also counted the interleaved stores'
+  // completion, so chunk 0 of every item stalled on HBM round trips.
+  auto init_pixel = [&](const Item& it, const i32x4& rrs_in, int p) {
+#ifdef CMF_DBG_STAMP                               // the stamp code's divergent branches push the descriptor into VGPRs
+    i32x4 rrs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rrs[i] = __builtin_amdgcn_readfirstlane(rrs_in[i]);
+#else
+    const i32x4& rrs = rrs_in;
+#endif
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int so = it.rpix + 4 * (p * r_px + c * 16 * r_co);
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(acc[p][c]) : "v"(rvoff), "s"(rrs), "s"(so) : "memory");
     }
   };
   auto store_pixel = [&](const Item& it, int p) {
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-      const f32x4 v = acc[p][c] + it.bias[c];                      // per-channel constant (primal bias)
+      const f32x4 v = acc[p][c] + bias[c];                         // per-channel constant (primal bias)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, v), cur_yrs, yvoff,
                                              it.ypix + 4 * (p * y_px + c * 16 * y_co), 0);
     }
   };
+  // Pixel p's residual has landed when at most N VMEM operations issued after it are outstanding.  The tail issues,
+  // per pixel, CW stores then CW loads, so after pixel p's loads come 2*CW*(PW-1-p) operations of the same tail
+  // (+ 2*CW*p of THIS chunk's tail when the item has a single chunk).
+  auto wait_res = [&](int p, bool also_last) {
+    static_assert(CW == 2 || CW == 1, "operand list below");
+    const int n = 2 * CW * (PW - 1 - p) + (also_last ? 2 * CW * p : 0);
+    if constexpr (CW == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(acc[p][0]), "+v"(acc[p][1]) : "n"(n));
+    else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(acc[p][0]) : "n"(n));
+  };
 
-  // One 8-channel chunk from LDS stage `stage`.  LAST = the item's final chunk: pixel p's accumulators are final
-  // after its K-step-2 MFMAs, so its 16-byte stores are issued right there and the NEXT item's residual loads go
-  // straight into the freed registers -- the VMEM issue cost of the tail (measured ~335 cycles per store / load
-  // instruction, ~9.4k + ~9k cycles per item when done as a block) hides under the remaining MFMAs.
-  auto chunk = [&](int stage, auto LAST) {
+  // One 8-channel chunk from LDS stage `stage`, PIXEL-MAJOR: all three K-steps of pixel 0, then pixel 1, ...  With
+  // the K-step-major order every pixel finished at the very end of the item's last chunk and was needed again at the
+  // very start of the next item's first chunk: the residual loads had a third of a chunk to arrive and the MFMA waves
+  // sat out an HBM round trip per item (the 15-20k-cycle "tail").  Now pixel p is final after (p+1)/PW of the LAST
+  // chunk -- its stores and the next item's residual loads are issued right there -- and is first touched at p/PW of
+  // the next FIRST chunk: every residual load has (PW-1)/PW of a chunk period to land.
+  auto chunk = [&](int stage, auto FIRST, auto LAST) {
 #ifdef CMF_DBG_NOMFMA
     if (LAST) {                                    // timing-only build: the MFMA waves only run the tail and the barriers
 #pragma unroll
@@ -525,35 +557,34 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     const unsigned char* Xl = Xh + C::XS_BYTES;
     const unsigned char* Wh = Xh + 2 * C::XS_BYTES;
     const unsigned char* Wl = Wh + C::WS_BYTES;
-    bf16x8 ah[2][CW], al[2][CW], bh[BD], bl[BD];
-    auto load_a = [&](int s, int set) {
-#pragma unroll
-      for (int c = 0; c < CW; ++c) {
-        ah[set][c] = *reinterpret_cast<const bf16x8*>(Wh + (((s * COT + c) * 64) << 4) + aoff);
-        al[set][c] = *reinterpret_cast<const bf16x8*>(Wl + (((s * COT + c) * 64) << 4) + aoff);
-      }
-    };
-    auto load_b = [&](int t) {
-      const int s = t / PW, p = t % PW;
+    bf16x8 ah[3][CW], al[3][CW], bh[BD], bl[BD];
+    auto load_b = [&](int t) {                                     // step t = 3*p + s
+      const int s = t % 3, p = t / 3;
       bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][p & 1] + p * 256);
       bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][p & 1] + p * 256);
     };
-    load_a(0, 0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        ah[s][c] = *reinterpret_cast<const bf16x8*>(Wh + (((s * COT + c) * 64) << 4) + aoff);
+        al[s][c] = *reinterpret_cast<const bf16x8*>(Wl + (((s * COT + c) * 64) << 4) + aoff);
+      }
 #pragma unroll
     for (int t = 0; t < BD - 1; ++t) load_b(t);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NSTEP; ++t) {
-      const int s = t / PW, p = t % PW;
+      const int s = t % 3, p = t / 3;
       if (t + BD - 1 < NSTEP) load_b(t + BD - 1);
-      if (p == 0 && s + 1 < 3) load_a(s + 1, (s + 1) & 1);
+      if (FIRST && s == 0) wait_res(p, LAST);
 #pragma unroll
       for (int c = 0; c < CW; ++c) {
         // D[row = Jacobian column][col = output channel] = X-fragment (as A) x W-fragment (as B): each lane then
         // holds 4 CONSECUTIVE columns (rows kq*4 + r) of channel cl -> 16-byte stores / residual loads
-        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], al[s & 1][c], acc[p][c], 0, 0, 0);
-        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s & 1][c], acc[p][c], 0, 0, 0);
-        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s & 1][c], acc[p][c], 0, 0, 0);
+        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], al[s][c], acc[p][c], 0, 0, 0);
+        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
+        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
       }
       if (LAST && s == 2) {
         store_pixel(cur, p);
@@ -567,25 +598,43 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 
   int g = 0;                                                       // stream chunk index -> LDS stage g & 1
 #pragma unroll
-  for (int p = 0; p < PW; ++p) init_pixel(cur, cur_rrs, p);
+  for (int p = 0; p < PW; ++p) init_pixel(cur, nxt_rrs, p);
+  // item 0: a block of loads, not the tail pattern (+ the bias)
+  static_assert(CW == 2 || CW == 1, "operand list below");
+  if constexpr (CW == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1])::"memory");
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0])::"memory");
   __syncthreads();                                                 // stage 0 ready
   for (int item = 0; item < n_items; ++item) {
     const bool has_next = item + 1 < n_items;
-    for (int ch = 0; ch < nchunks - 1; ++ch, ++g) {
-      chunk(g & 1, std::false_type{});
-      __syncthreads();                                             // stage (g+1)&1 ready, stage g&1 free
-    }
-    // the next item's context is derived right before the chunk that uses it (carried across the chunk loop the
-    // descriptors ended up in VGPRs + waterfall loops)
     auto nxt_yrs = cur_yrs;
-    {
+    auto next_context = [&]() {                                    // derived right before the chunk that uses it
       int np, slice, cog;
       item_geom(has_next ? item + 1 : item, np, slice, cog, nxt);
       nxt_yrs = y_rsrc(np, slice, cog);
       nxt_rrs = r_rsrc(np, slice, cog, has_next);                  // last item: zero records, nothing is fetched
+    };
+    {                                                              // nchunks >= 2 (launcher precondition: a chunk that
+                                                                   // is FIRST and LAST at once spilled 130 VGPRs)
+      STAMP(0, g, 0);
+      chunk(g & 1, std::true_type{}, std::false_type{});
+      STAMP(0, g, 1);
+      __syncthreads();                                             // stage (g+1)&1 ready, stage g&1 free
+      STAMP(0, g, 2);
+      ++g;
+      for (int ch = 1; ch < nchunks - 1; ++ch, ++g) {
+        STAMP(0, g, 0);
+        chunk(g & 1, std::false_type{}, std::false_type{});
+        STAMP(0, g, 1);
+        __syncthreads();
+        STAMP(0, g, 2);
+      }
+      next_context();
+      STAMP(0, g, 0);
+      chunk(g & 1, std::false_type{}, std::true_type{});
+      STAMP(0, g, 1);
+      __syncthreads();
+      STAMP(0, g, 2);
     }
-    chunk(g & 1, std::true_type{});
-    __syncthreads();
     ++g;
     cur = nxt;
     cur_yrs = nxt_yrs;
@@ -667,11 +716,11 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   if (!ap) return CMF_EINVAL;
   const cmf_conv_tangent_args& a = *ap;
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
-  if (a.taps != 9 || a.cin % 8 || a.nc <= 0 || a.nc % 16) return CMF_EINVAL;
+  if (a.taps != 9 || a.cin % 8 || a.cin < 16 || a.nc <= 0 || a.nc % 16) return CMF_EINVAL;
   if (a.fmode <= CMF_F_NONE || a.fmode > CMF_F_SELF_RELU) return CMF_EINVAL;   // NONE: use cmf_conv_tangent (the loader's
                                                                               // load schedule always carries a factor stream)
   if (a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
-  if ((a.x_np | a.x_ci | a.x_px) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
+  if ((a.x_np | a.x_ci | a.x_px | a.x_sl | a.y_sl | a.r_sl) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
   if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;            // 16-byte stores
   if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;    // 16-byte residual loads
   const long long HW = (long long)a.H * a.W;
@@ -683,5 +732,6 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   // only the 7-pixel-per-wave tiling is built (14- and 28-wide images); the kernel has no partial-tile / partial-channel-
   // group code: whole 2 x 14 tiles and whole groups of 64 (or exactly 32) output channels only
   if (a.W % 14 || a.H % 2 || !(a.cout % 64 == 0 || a.cout == 32)) return CMF_EINVAL;
+  if (a.bias && a.cout > 64) return CMF_EINVAL;                 // the per-channel constants are fetched once per launch
   return launch_cot<7>(a, s);
 }

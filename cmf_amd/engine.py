@@ -79,7 +79,7 @@ TANGENT_PRECISION = "bf16x3"
 
 def _use_bf16x3(taps, cin, W, transpose, H=None, cout=64):
     """Shapes the split-precision kernel is built for: whole 2 x 14 pixel tiles, whole 64- (or one 32-) channel groups."""
-    return (TANGENT_PRECISION == "bf16x3" and taps == 9 and cin % 8 == 0 and W % 14 == 0 and (H is None or H % 2 == 0)
+    return (TANGENT_PRECISION == "bf16x3" and taps == 9 and cin % 8 == 0 and cin >= 16 and W % 14 == 0 and (H is None or H % 2 == 0)
             and (cout % 64 == 0 or cout == 32) and not transpose)
 
 
@@ -173,7 +173,8 @@ def conv_primal(x_ptr_t, x_off, x_b, x_c, x_px, weight, taps, bias, y, y_b, y_c,
 
 
 def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_px, np_, cin, cout, H, W, nc,
-                 fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, res_t=None, transpose=False, bias=None, f_group=1):
+                 fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, res_t=None, transpose=False, bias=None, f_group=1,
+                 x_sl=16, y_sl=16):
     lib = _lib.load()
     a = ConvTangentArgs()
     a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
@@ -184,6 +185,7 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     a.r = _p(res_t); a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
     a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), int(taps)
     a.bias = _p(bias); a.f_group = int(f_group)
+    a.x_sl, a.y_sl, a.r_sl = int(x_sl), int(y_sl), int(y_sl)
     fn, what = (lib.cmf_conv_tangent_bf16x3, "cmf_conv_tangent_bf16x3") if split else (lib.cmf_conv_tangent, "cmf_conv_tangent")
     launch = lambda: _lib.check(fn(C.byref(a), _stream()), what)
     if TIMER is None:
@@ -453,23 +455,29 @@ def net_tangent(net, T, view, acts, transpose_packs=False):
         hid, cout, H, W, HW = conv0.out_channels, convf.out_channels, geo.H, geo.W, geo.HW
         new = lambda c: Tangent(B, c * HW, nc, "panel", dev)
         pn = lambda c: (c * HW * nc, HW * nc, nc)          # (np, chan, px) strides of a panel with c channels
+        # Hidden tangents live SLICE-MAJOR, [sample][pixel][16-column slice][channel][16]: the 16 channels x 16 columns an
+        # MFMA wave stores (or reads as residual) per instruction are then one contiguous KiB instead of sixteen 64-byte
+        # pieces in sixteen channel planes -- that access shape ran at 13 B/clk/CU against 48 (tools/ubench/curate2.py)
+        # and was the 15k-cycle tail of every work item.  Only the kernels' strides know about it.
+        hd = (hid * HW * nc, 16, hid * nc)                   # (np, chan, px)
+        hsl = hid * 16                                       # slice stride
         h = new(hid)
-        conv_tangent(T.data, view.chan_off * HW * nc, T.t_b, view.chan_step * HW * nc, nc, conv0.weight, 9, h.data, *pn(hid),
+        conv_tangent(T.data, view.chan_off * HW * nc, T.t_b, view.chan_step * HW * nc, nc, conv0.weight, 9, h.data, *hd,
                      B, view.cin, hid, H, W, nc, fmode=F_RAW if view.mask is not None else F_NONE, f=view.mask, f_np=0,
-                     f_ci=HW, f_px=1)
+                     f_ci=HW, f_px=1, y_sl=hsl)
         fg = getattr(acts, "f_group", 1)                     # primal activations: (B,C,H,W) or (B/16,C,H,W,16)
         fs = dict(f_np=hid * HW * fg, f_ci=HW * fg, f_px=fg, f_group=fg)
         u, h2 = new(hid), new(hid)
         for k, blk in enumerate(blocks):
             a_in, c1 = acts[2 * k], acts[2 * k + 1]
-            conv_tangent(h.data, 0, *pn(hid), blk.conv1.weight, 9, u.data, *pn(hid), B, hid, hid, H, W, nc, fmode=F_RELU,
-                         f=a_in, **fs)
-            conv_tangent(u.data, 0, *pn(hid), blk.conv2.weight, 9, h2.data, *pn(hid), B, hid, hid, H, W, nc, fmode=F_RELU,
-                         f=c1, res_t=h.data, **fs)
+            conv_tangent(h.data, 0, *hd, blk.conv1.weight, 9, u.data, *hd, B, hid, hid, H, W, nc, fmode=F_RELU,
+                         f=a_in, x_sl=hsl, y_sl=hsl, **fs)
+            conv_tangent(u.data, 0, *hd, blk.conv2.weight, 9, h2.data, *hd, B, hid, hid, H, W, nc, fmode=F_RELU,
+                         f=c1, res_t=h.data, x_sl=hsl, y_sl=hsl, **fs)
             h, h2 = h2, h
         yt = new(cout)
-        conv_tangent(h.data, 0, *pn(hid), convf.weight, 1, yt.data, *pn(cout), B, hid, cout, H, W, nc, fmode=F_RELU,
-                     f=acts[-1], **fs)
+        conv_tangent(h.data, 0, *hd, convf.weight, 1, yt.data, *pn(cout), B, hid, cout, H, W, nc, fmode=F_RELU,
+                     f=acts[-1], x_sl=hsl, **fs)
         return yt
     lins = [m for m in net if isinstance(m, nn.Linear)]
     x_t, x_off, x_ci, cin = T.data, view.chan_off * B * nc, view.chan_step * B * nc, view.cin

@@ -73,10 +73,15 @@ typedef struct {
   int f_group;                                  /* >1: the factor tensor is sample-grouped: element (np, ci, px)
                                                    lives at f[(np / f_group)*f_np + ci*f_ci + px*f_px + np % f_group]
                                                    (primal activations kept in the "16 samples as columns" layout) */
+  long long x_sl, y_sl, r_sl;                   /* element stride between 16-column slices: column col of x lives at
+                                                   (col / 16)*x_sl + col % 16 (likewise y, r).  0 means 16 = plain
+                                                   contiguous columns.  The slice-major hidden layout
+                                                   [pixel][slice][channel][16] (x_px = C*nc, x_sl = C*16, x_ci = 16)
+                                                   makes a wave's 16 channels x 16 columns one contiguous KiB        */
 } cmf_conv_tangent_args;
 int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
 
-/* Split-precision variant of cmf_conv_tangent for taps == 9, cin % 8 == 0, W % 14 == 0, H % 2 == 0 and
+/* Split-precision variant of cmf_conv_tangent for taps == 9, cin % 8 == 0, cin >= 16, W % 14 == 0, H % 2 == 0 and
  * cout % 64 == 0 or cout == 32 (anything else: CMF_EINVAL, use cmf_conv_tangent): operands are split
  * v = hi + lo (bf16 each) and multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
  * accumulation (fp32-grade result, ~2^-16 relative per product).  `w` must come from

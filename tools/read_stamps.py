@@ -11,8 +11,9 @@ B, H, nc, ch = 128, 28, 64, 64; HW = H * H
 x = torch.randn(B, ch, H, H, nc, device="cuda"); prim = torch.randn(B, ch, H, H, device="cuda")
 r = torch.randn(B, ch, H, H, nc, device="cuda") if res else None
 y = torch.empty(B, ch, H, H, nc, device="cuda"); w = torch.nn.Parameter(torch.randn(ch, ch, 3, 3, device="cuda") / 24)
+st, sl = (ch*HW*nc, 16, ch*nc), ch*16          # slice-major hidden layout
 def run():
-    E.conv_tangent(x, 0, ch*HW*nc, HW*nc, nc, w, 9, y, ch*HW*nc, HW*nc, nc, B, ch, ch, H, H, nc, fmode=E.F_RELU, f=prim, f_np=ch*HW, f_ci=HW, f_px=1, res_t=r)
+    E.conv_tangent(x, 0, *st, w, 9, y, *st, B, ch, ch, H, H, nc, fmode=E.F_RELU, f=prim, f_np=ch*HW, f_ci=HW, f_px=1, res_t=r, x_sl=sl, y_sl=sl)
 for _ in range(3): run()
 torch.cuda.synchronize()
 buf = np.zeros((3, 64, 4), dtype=np.uint64)
@@ -22,7 +23,7 @@ M, L = buf[0].astype(np.int64), buf[1].astype(np.int64)
 t0 = M[0, 0]
 print("MFMA wave: g  start  compute  barrier_wait   (cycles @100MHz*? raw s_memtime units)")
 for g in range(24):
-    print(f"  g={g:2d} start={M[g,0]-t0:8d} compute={M[g,1]-M[g,0]:6d} barrier={M[g,2]-M[g,1]:6d}")
+    print(f"  g={g:2d} start={M[g,0]-t0:8d} compute={M[g,1]-M[g,0]:6d} barrier={M[g,2]-M[g,1]:6d} next_ctx={max(M[g,3]-M[g,0],0):6d}")
 print("loader wave: g  start  prefetch_issue  wait_loads  commit  (then barrier)")
 for g in range(24):
     print(f"  g={g:2d} start={L[g,0]-t0:8d} issue={L[g,1]-L[g,0]:6d} wait={L[g,2]-L[g,1]:6d} commit={L[g,3]-L[g,2]:6d} next_start-gap={L[g+1,0]-L[g,3]:6d}")
