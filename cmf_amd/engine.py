@@ -193,7 +193,7 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     # algorithmic work of this launch: 2*cin*cout*taps FLOP per output pixel and Jacobian column; every input,
     # output and residual element crosses HBM once (4 bytes each)
     px = float(H) * W * nc * np_
-    TIMER.wrap(f"conv_tangent_t{taps}_ci{cin}_co{cout}", 2.0 * cin * cout * taps * px,
+    TIMER.wrap(f"conv_tangent_t{taps}_ci{cin}_co{cout}" + ("_primal" if fmode == F_SELF_RELU else ""), 2.0 * cin * cout * taps * px,
                4.0 * px * (cin + cout + (cout if res_t is not None else 0)), launch)
 
 

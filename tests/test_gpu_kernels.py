@@ -17,11 +17,16 @@ def rel(a, b):
 ])
 @pytest.mark.parametrize("fmode", ["none", "relu", "tanh", "raw"])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
-def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, monkeypatch):
+@pytest.mark.parametrize("layout", ["panel", "slice"])
+def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, monkeypatch):
+    """layout 'panel' = [sample][channel][pixel][nc]; 'slice' = the slice-major hidden layout
+    [sample][pixel][16-column slice][channel][16] addressed through x_sl / y_sl (include/cmf_amd.h)."""
     from cmf_amd import engine as E
     monkeypatch.setattr(E, "TANGENT_PRECISION", precision)
-    if precision == "bf16x3" and not E._use_bf16x3(taps, cin, W, False):
-        pytest.skip("shape not covered by the split-precision kernel (falls back to fp32)")
+    if precision == "bf16x3" and (not E._use_bf16x3(taps, cin, W, False, H, cout) or fmode == "none"):
+        pytest.skip("shape / mode not covered by the split-precision kernel (the engine falls back to fp32)")
+    if layout == "slice" and (cin, cout, H) not in ((64, 64, 14), (64, 64, 28), (2, 64, 14), (64, 4, 14), (16, 40, 5)):
+        pytest.skip("slice-major layout: a subset of the shapes is enough")
     gen = torch.Generator().manual_seed(cin * 1000 + cout + H)
     B = 3
     w = torch.randn(cout, cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1, generator=gen) / (cin * taps) ** 0.5
@@ -35,10 +40,23 @@ def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, monkeypatch):
     want = F.conv2d(xin, w, padding=1 if taps == 9 else 0).reshape(B, nc, cout, H, W).permute(0, 2, 3, 4, 1) + res
     HW = H * W
     wd = torch.nn.Parameter(w.cuda())
-    y = torch.full((B, cout, H, W, nc), float("nan"), device="cuda")
-    E.conv_tangent(x.cuda(), 0, cin * HW * nc, HW * nc, nc, wd, taps, y, cout * HW * nc, HW * nc, nc, B, cin, cout, H, W, nc,
+    if layout == "panel":
+        to_dev = lambda t: t.cuda()
+        from_dev = lambda t, c: t
+        st = lambda c: (c * HW * nc, HW * nc, nc)
+        sl = lambda c: 16
+    else:
+        S = nc // 16
+        to_dev = lambda t: t.reshape(B, -1, HW, S, 16).permute(0, 2, 3, 1, 4).contiguous().cuda()
+        from_dev = lambda t, c: t.reshape(B, HW, S, c, 16).permute(0, 3, 1, 2, 4).reshape(B, c, H, W, nc)
+        st = lambda c: (c * HW * nc, 16, c * nc)
+        sl = lambda c: c * 16
+    y = torch.full((B * cout * HW * nc,), float("nan"), device="cuda")
+    E.conv_tangent(to_dev(x), 0, *st(cin), wd, taps, y, *st(cout), B, cin, cout, H, W, nc,
                    fmode={"none": E.F_NONE, "relu": E.F_RELU, "tanh": E.F_TANH, "raw": E.F_RAW}[fmode],
-                   f=None if src is None else src.cuda(), f_np=cin * HW, f_ci=HW, f_px=1, res_t=res.cuda())
+                   f=None if src is None else src.cuda(), f_np=cin * HW, f_ci=HW, f_px=1, res_t=to_dev(res),
+                   x_sl=sl(cin), y_sl=sl(cout))
+    y = from_dev(y, cout).reshape(B, cout, H, W, nc)
     # bf16x3: ~2^-16 per product, well inside the same bound as the fp32 kernel for these K sizes
     assert rel(y, want) < 2e-5
 
