@@ -54,6 +54,10 @@ struct BCfg {
   static constexpr int XS_BYTES = PIXH * 16 * 16;                 // one of hi / lo
   static constexpr int WS_BYTES = 3 * COT * 4 * 16 * 16;          // one of hi / lo
   static constexpr int BUF_BYTES = 2 * XS_BYTES + 2 * WS_BYTES;   // one pipeline stage
+  // centre ring: the tile's own pixels (no halo) of three octets, hi and lo, for the 4-octet centre-tap K-step
+  static constexpr int RING_HALF = 2 * TW * 16 * 16;               // one of hi / lo of one octet: 2 rows x TW pixels x 256 B
+  static constexpr int RING_SLOT = 2 * RING_HALF;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES + 3 * RING_SLOT;
   static constexpr int W_CHUNK_BYTES = 2 * 3 * 4 * 4 * 16 * 16;   // global: [hl][s][cot 4][kq][co][8] bf16 = 24 KiB
   static constexpr int NX_ITEMS = PIXH * 4;                       // (pixel, column quad): one per loader thread
   static constexpr int NW_ITEMS = 2 * 3 * COT * 4 * 16;           // 16-byte items of the W chunk actually used
@@ -420,21 +424,34 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // Per-lane B offsets: lane group kq of K-step s reads tap 4*s + kq (taps >= 9 read tap 8's data against zero
   // weights) of pixel (wrow + dy, p + dx); the slot permutation depends on the pixel's parity, i.e. on (dx + p) & 1
   // (the halo row length TWH is even).
-  int boff[3][2];
+  // K mapping WITHOUT padding: K-step 0 = taps 0..3, K-step 1 = taps 5..8 of the chunk's octet (lane group kq = tap);
+  // the centre taps (tap 4) of FOUR consecutive octets form one K-step (lane group kq = octet 4m + kq), executed in
+  // every fourth chunk: 9 K-steps per 4 octets instead of 12.  The centre pixels of octets 4m .. 4m+2 wait in a small LDS
+  // ring (copied from the stage by the MFMA waves while they consume it), octet 4m+3's are read from the live stage.
+  int boff[2][2];
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    int tap = 4 * s + kq;
-    tap = tap < 9 ? tap : 8;
+  for (int s = 0; s < 2; ++s) {
+    const int tap = s == 0 ? kq : 5 + kq;
     const int pbase = (wrow + tap / 3) * C::TWH + tap % 3;         // staged pixel of p = 0
 #pragma unroll
     for (int par = 0; par < 2; ++par) boff[s][par] = ((pbase * 16 + xslot(cl, pbase + par)) << 4);
+  }
+  // centre K-step: per-lane source (ring slot kq for kq < 3, the live stage for kq == 3), relative to smem.  Ring rows
+  // are verbatim copies of the stage's pixel rows, so the slot permutation is the stage's (parity of the halo pixel).
+  const int cpix = (wrow + 1) * C::TWH + 1;                        // halo index of this wave's pixel p = 0
+  int coff_ring[2], coff_stage[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int sl = xslot(cl, cpix + par) << 4;
+    coff_ring[par] = 2 * C::BUF_BYTES + (kq < 3 ? kq : 0) * C::RING_SLOT + wrow * C::TW * 256 + sl;
+    coff_stage[par] = cpix * 256 + sl;
   }
   const int aoff = (lane << 4) + ((cohalf * CW * 64) << 4);
 
   // Fragment pipeline: step t = s*PW + p consumes B fragment pair t; pairs are fetched BD-1 steps ahead into a ring
   // of BD register pairs, the A fragments of K-step s+1 are fetched at the start of K-step s into the alternate
   // set.  Everything is unrolled, so ring slots are static registers and hipcc emits counted lgkmcnt waits.
-  constexpr int BD = 4, NSTEP = 3 * PW;                            // step t = 3*p + s (pixel-major)
+  constexpr int BD = 4;
 
   // Item context.  The launcher guarantees whole tiles (H even, W % TW == 0) and whole channel groups, so the tail has
   // NO per-pixel / per-channel validity tests, and every access is a raw buffer op: descriptor base = the item's
@@ -504,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // Accumulator initial value of pixel p = residual, loaded straight into the accumulators by INLINE ASM with
   // hand-counted waits (wait_res below): hipcc's vmcnt for these loads also counted the interleaved stores'
   // completion, so chunk 0 of every item stalled on HBM round trips.
-  auto init_pixel = [&](const Item& it, const i32x4& rrs_in, int p) {
+  auto init_pixel = [&](const Item& it, const i32x4& rrs_in, int p) __attribute__((always_inline)) {
 #ifdef CMF_DBG_STAMP                               // the stamp code's divergent branches push the descriptor into VGPRs
     i32x4 rrs;
 #pragma unroll
@@ -518,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(acc[p][c]) : "v"(rvoff), "s"(rrs), "s"(so) : "memory");
     }
   };
-  auto store_pixel = [&](const Item& it, int p) {
+  auto store_pixel = [&](const Item& it, int p) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       const f32x4 v = acc[p][c] + bias[c];                         // per-channel constant (primal bias)
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // Pixel p's residual has landed when at most N VMEM operations issued after it are outstanding.  The tail issues,
   // per pixel, CW stores then CW loads, so after pixel p's loads come 2*CW*(PW-1-p) operations of the same tail
   // (+ 2*CW*p of THIS chunk's tail when the item has a single chunk).
-  auto wait_res = [&](int p, bool also_last) {
+  auto wait_res = [&](int p, bool also_last) __attribute__((always_inline)) {
     static_assert(CW == 2 || CW == 1, "operand list below");
     const int n = 2 * CW * (PW - 1 - p) + (also_last ? 2 * CW * p : 0);
     if constexpr (CW == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(acc[p][0]), "+v"(acc[p][1]) : "n"(n));
@@ -542,7 +559,9 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // sat out an HBM round trip per item (the 15-20k-cycle "tail").  Now pixel p is final after (p+1)/PW of the LAST
   // chunk -- its stores and the next item's residual loads are issued right there -- and is first touched at p/PW of
   // the next FIRST chunk: every residual load has (PW-1)/PW of a chunk period to land.
-  auto chunk = [&](int stage, auto FIRST, auto LAST) {
+  // always_inline: instantiated four ways but called eight times -- left as a call, everything captured by reference
+  // (accumulators, fragments) went through scratch and flat memory
+  auto chunk = [&](int stage, int ring_slot, auto FIRST, auto LAST, auto QUAD) __attribute__((always_inline)) {
 #ifdef CMF_DBG_NOMFMA
     if (LAST) {                                    // timing-only build: the MFMA waves only run the tail and the barriers
 #pragma unroll
@@ -553,31 +572,66 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     }
     return;
 #endif
+    constexpr int KS = QUAD ? 3 : 2, NSTEP = KS * PW;              // step t = KS*p + s (pixel-major)
     const unsigned char* Xh = smem + stage * C::BUF_BYTES;
     const unsigned char* Xl = Xh + C::XS_BYTES;
     const unsigned char* Wh = Xh + 2 * C::XS_BYTES;
     const unsigned char* Wl = Wh + C::WS_BYTES;
-    bf16x8 ah[3][CW], al[3][CW], bh[BD], bl[BD];
-    auto load_b = [&](int t) {                                     // step t = 3*p + s
-      const int s = t % 3, p = t / 3;
-      bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][p & 1] + p * 256);
-      bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][p & 1] + p * 256);
+    bf16x8 ah[KS][CW], al[KS][CW], bh[BD], bl[BD];
+    // centre K-step operands: lane groups 0..2 read the ring (hi at +0, lo at +RING_HALF), group 3 the live stage
+    const unsigned char* ch_[2];
+    const unsigned char* cl_[2];
+    if (QUAD) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        ch_[par] = smem + (kq < 3 ? coff_ring[par] : stage * C::BUF_BYTES + coff_stage[par]);
+        cl_[par] = smem + (kq < 3 ? coff_ring[par] + C::RING_HALF : stage * C::BUF_BYTES + C::XS_BYTES + coff_stage[par]);
+      }
+    }
+    auto load_b = [&](int t) {
+      const int s = t % KS, p = t / KS;
+      if (s < 2) {
+        bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][p & 1] + p * 256);
+        bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][p & 1] + p * 256);
+      } else {
+        bh[t % BD] = *reinterpret_cast<const bf16x8*>(ch_[p & 1] + p * 256);
+        bl[t % BD] = *reinterpret_cast<const bf16x8*>(cl_[p & 1] + p * 256);
+      }
     };
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int c = 0; c < CW; ++c) {
         ah[s][c] = *reinterpret_cast<const bf16x8*>(Wh + (((s * COT + c) * 64) << 4) + aoff);
         al[s][c] = *reinterpret_cast<const bf16x8*>(Wl + (((s * COT + c) * 64) << 4) + aoff);
       }
+    // non-QUAD chunk: park this octet's centre pixels in ring slot `ring_slot`: the two waves of a tile row split hi / lo,
+    // 14 pixel rows of 256 B = 224 sixteen-byte units per wave
+    u32x4 cp[4];
+    if (!QUAD) {
+      const unsigned char* src = (cohalf ? Xl : Xh) + cpix * 256;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int u = lane + 64 * k;
+        if (u < PW * 16) cp[k] = *reinterpret_cast<const u32x4*>(src + u * 16);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < BD - 1; ++t) load_b(t);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NSTEP; ++t) {
-      const int s = t % 3, p = t / 3;
+      const int s = t % KS, p = t / KS;
       if (t + BD - 1 < NSTEP) load_b(t + BD - 1);
-      if (FIRST && s == 0) wait_res(p, LAST);
+      if (!QUAD && t == 2) {                                       // the copy's reads have long landed
+        unsigned char* dst = smem + 2 * C::BUF_BYTES + ring_slot * C::RING_SLOT + (cohalf ? C::RING_HALF : 0) + wrow * C::TW * 256;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int u = lane + 64 * k;
+          if (u < PW * 16) *reinterpret_cast<u32x4*>(dst + u * 16) = cp[k];
+        }
+      }
+      if (FIRST && s == 0) wait_res(p, false);
 #pragma unroll
       for (int c = 0; c < CW; ++c) {
         // D[row = Jacobian column][col = output channel] = X-fragment (as A) x W-fragment (as B): each lane then
@@ -586,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
         acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
       }
-      if (LAST && s == 2) {
+      if (LAST && s == KS - 1) {
         store_pixel(cur, p);
         init_pixel(nxt, nxt_rrs, p);
       }
@@ -607,35 +661,36 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   for (int item = 0; item < n_items; ++item) {
     const bool has_next = item + 1 < n_items;
     auto nxt_yrs = cur_yrs;
-    auto next_context = [&]() {                                    // derived right before the chunk that uses it
+    auto next_context = [&]() __attribute__((always_inline)) {                                   // derived right before the chunk that uses it
       int np, slice, cog;
       item_geom(has_next ? item + 1 : item, np, slice, cog, nxt);
       nxt_yrs = y_rsrc(np, slice, cog);
       nxt_rrs = r_rsrc(np, slice, cog, has_next);                  // last item: zero records, nothing is fetched
     };
-    {                                                              // nchunks >= 2 (launcher precondition: a chunk that
-                                                                   // is FIRST and LAST at once spilled 130 VGPRs)
+    // nchunks = 4 G (launcher precondition): chunks 4m, 4m+1, 4m+2 run two K-steps and park their centre pixels, chunk
+    // 4m+3 adds the four-octet centre K-step; the item's first chunk waits for the residual, its last one stores.
+    // Written out as a fixed sequence (a run-time variant switch inside one loop body spilled 189 VGPRs).
+    auto step = [&](auto FIRST, auto LAST, auto QUAD, auto SLOT) __attribute__((always_inline)) {
       STAMP(0, g, 0);
-      chunk(g & 1, std::true_type{}, std::false_type{});
+      chunk(g & 1, decltype(SLOT)::value, FIRST, LAST, QUAD);
       STAMP(0, g, 1);
       __syncthreads();                                             // stage (g+1)&1 ready, stage g&1 free
       STAMP(0, g, 2);
       ++g;
-      for (int ch = 1; ch < nchunks - 1; ++ch, ++g) {
-        STAMP(0, g, 0);
-        chunk(g & 1, std::false_type{}, std::false_type{});
-        STAMP(0, g, 1);
-        __syncthreads();
-        STAMP(0, g, 2);
-      }
-      next_context();
-      STAMP(0, g, 0);
-      chunk(g & 1, std::false_type{}, std::true_type{});
-      STAMP(0, g, 1);
-      __syncthreads();
-      STAMP(0, g, 2);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    step(T{}, F{}, F{}, std::integral_constant<int, 0>{});
+    step(F{}, F{}, F{}, std::integral_constant<int, 1>{});
+    step(F{}, F{}, F{}, std::integral_constant<int, 2>{});
+    for (int m = 1; m < nchunks / 4; ++m) {
+      step(F{}, F{}, T{}, std::integral_constant<int, 0>{});
+      step(F{}, F{}, F{}, std::integral_constant<int, 0>{});
+      step(F{}, F{}, F{}, std::integral_constant<int, 1>{});
+      step(F{}, F{}, F{}, std::integral_constant<int, 2>{});
     }
-    ++g;
+    next_context();
+    step(F{}, T{}, T{}, std::integral_constant<int, 0>{});
     cur = nxt;
     cur_yrs = nxt_yrs;
   }
@@ -654,7 +709,14 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned 
   t >>= 1;
   const int nchunks = cin / 8;
   const int ch = (int)(t % nchunks), cog = (int)(t / nchunks);
-  const int co = cog * 64 + cot * 16 + col, ci = ch * 8 + j, tap = 4 * s + kq;
+  // K-step 0: taps 0..3, K-step 1: taps 5..8 of octet ch (lane group kq = tap); K-step 2 (used in chunks ch % 4 == 3
+  // only): the CENTRE tap of octets ch-3 .. ch (lane group kq = octet)
+  const int co = cog * 64 + cot * 16 + col;
+  int ci = ch * 8 + j, tap = s == 0 ? kq : 5 + kq;
+  if (s == 2) {
+    tap = (ch & 3) == 3 ? 4 : 9;
+    ci = (ch - 3 + kq) * 8 + j;
+  }
   float v = 0.f;
   if (co < cout && tap < 9) v = w[((long long)co * cin + ci) * 9 + tap];
   const __bf16 h = (__bf16)v;
@@ -671,7 +733,7 @@ int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
   auto k = conv_tangent_bf16x3_kernel<COT, PXW, SELF>;
-  constexpr int lds = 2 * C::BUF_BYTES;
+  constexpr int lds = C::LDS_BYTES;
   static int n_cu = 0;                          // idempotent initialisation; a benign race at worst repeats it
   if (n_cu == 0) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -716,7 +778,7 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   if (!ap) return CMF_EINVAL;
   const cmf_conv_tangent_args& a = *ap;
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
-  if (a.taps != 9 || a.cin % 8 || a.cin < 16 || a.nc <= 0 || a.nc % 16) return CMF_EINVAL;
+  if (a.taps != 9 || a.cin % 32 || a.nc <= 0 || a.nc % 16) return CMF_EINVAL;   // K packing works on groups of 4 octets
   if (a.fmode <= CMF_F_NONE || a.fmode > CMF_F_SELF_RELU) return CMF_EINVAL;   // NONE: use cmf_conv_tangent (the loader's
                                                                               // load schedule always carries a factor stream)
   if (a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
