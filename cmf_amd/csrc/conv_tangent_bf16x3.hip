@@ -96,9 +96,13 @@ __device__ __forceinline__ int xslot(int col, int pix) { return (((col & 3) << 2
 // Two LDS stages (2 x 56 KiB), ONE barrier per 8-channel chunk; both roles execute the same number of barriers.
 // SELF = the input's own elementwise relu is applied on load (primal data in the column slots); a compile-time switch:
 // as a run-time select it made hipcc spill 77 VGPRs in the loader's commit.
-template <int COT, int PXW, bool SELF>
+template <int COT, int PXW, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
                                                                        int nslices, int ncog, int total) {
+  // MODE: 0 = general factor formula, 1 = relu factor (2 instead of 6 VALU per channel in the loader), 2 = SELF (the
+  // input's own relu, no factor stream).  Compile-time: every loader VALU instruction delays the MFMA wave it shares
+  // a SIMD with.
+  constexpr bool SELF = MODE == 2, RELU = MODE == 1;
   using C = BCfg<COT, PXW>;
   constexpr int CW = COT / 2, PW = 2 * PXW;
   static_assert(COT % 2 == 0, "the co-split wave layout needs an even number of output-channel tiles");
@@ -341,7 +345,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float f = r.f[j];
-          const float m = r.okf * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
+          const float m = SELF ? r.okf : RELU ? (f > 0.f ? r.okf : 0.f)
+                                              : r.okf * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[j][c] = (SELF ? fmaxf(r.x[j][c], 0.f) : r.x[j][c]) * m;
         }
@@ -725,14 +730,14 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned 
   out[i] = __builtin_bit_cast(unsigned short, r);
 }
 
-template <int COT, int PXW, bool SELF>
+template <int COT, int PXW, int MODE>
 int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   using C = BCfg<COT, PXW>;
   const int tiles_x = cmf_ceil_div(a.W, 2 * PXW), tiles = tiles_x * cmf_ceil_div(a.H, 2);
   const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
-  auto k = conv_tangent_bf16x3_kernel<COT, PXW, SELF>;
+  auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE>;
   constexpr int lds = C::LDS_BYTES;
   static int n_cu = 0;                          // idempotent initialisation; a benign race at worst repeats it
   if (n_cu == 0) {
@@ -754,8 +759,10 @@ int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
 
 template <int PXW>
 int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
-  if (a.fmode == CMF_F_SELF_RELU) return (a.cout > 32) ? launch<4, PXW, true>(a, s) : launch<2, PXW, true>(a, s);
-  return (a.cout > 32) ? launch<4, PXW, false>(a, s) : launch<2, PXW, false>(a, s);   // co tiles per workgroup: 64 / 32 channels
+  // co tiles per workgroup: 64 / 32 channels; factor code specialised for self-relu / relu / anything else
+  if (a.fmode == CMF_F_SELF_RELU) return (a.cout > 32) ? launch<4, PXW, 2>(a, s) : launch<2, PXW, 2>(a, s);
+  if (a.fmode == CMF_F_RELU) return (a.cout > 32) ? launch<4, PXW, 1>(a, s) : launch<2, PXW, 1>(a, s);
+  return (a.cout > 32) ? launch<4, PXW, 0>(a, s) : launch<2, PXW, 0>(a, s);
 }
 
 inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 29); }   // element offsets; x4 bytes must fit 32 bits
