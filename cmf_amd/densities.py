@@ -273,7 +273,7 @@ class FlowProgram:
     (non_square.py:146-188), which the reference rebuilds on every call."""
 
     #: bytes of tangent activations one sub-batch may occupy (three hidden panels + J + net output)
-    TANGENT_BUDGET = 64 << 30
+    TANGENT_BUDGET = 160 << 30                      # of the 288 GB; C3 at B = 512 needs ~20 GB, C5 at B = 256 ~45 GB
 
     def __init__(self, head):
         self.layers = []
@@ -479,6 +479,13 @@ class NonSquareHeadDensity(Density):
         if want_jac:
             per = prog.tangent_bytes_per_sample(E.ceil16(prog.d))
             chunk = max(1, min(B, prog.TANGENT_BUDGET // max(per, 1)))
+            if chunk < B:
+                # equal sub-batches, multiples of 16 where possible: the primal pass groups 16 samples per column slot,
+                # and a ragged last sub-batch would run the per-16 paths underfilled
+                n = -(-B // chunk)
+                chunk = -(-B // n)
+                if chunk >= 16:
+                    chunk = min(chunk + (-chunk) % 16, B)
         outs = [self._elbo_chunk(x[i:i + chunk], want_lik, want_jac, add_reconstruction, add_diagonal_metric_reg,
                                  add_offdiagonal_metric_reg, likelihood_wt, metric_wt, ood,
                                  None if _pre_logjac is None else _pre_logjac[i:i + chunk])
