@@ -798,9 +798,10 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
       HW > (1 << 24))
     return CMF_ERANGE;
   hipStream_t s = (hipStream_t)stream;
-  // only the 7-pixel-per-wave tiling is built (14- and 28-wide images); the kernel has no partial-tile / partial-channel-
-  // group code: whole 2 x 14 tiles and whole groups of 64 (or exactly 32) output channels only
-  if (a.W % 14 || a.H % 2 || !(a.cout % 64 == 0 || a.cout == 32)) return CMF_EINVAL;
+  // the kernel has no partial-tile / partial-channel-group code: whole 2 x 14 tiles (14- and 28-wide images) or whole
+  // 2 x 8 tiles (16- / 32-wide: CIFAR; 160 of the 256 loader threads busy, so loader-bound) and whole groups of 64 (or
+  // exactly 32) output channels only
+  if ((a.W % 14 && a.W % 8) || a.H % 2 || !(a.cout % 64 == 0 || a.cout == 32)) return CMF_EINVAL;
   if (a.bias && a.cout > 64) return CMF_EINVAL;                 // the per-channel constants are fetched once per launch
-  return launch_cot<7>(a, s);
+  return a.W % 14 == 0 ? launch_cot<7>(a, s) : launch_cot<4>(a, s);
 }
