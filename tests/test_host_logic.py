@@ -206,3 +206,38 @@ def test_dequantization_mutates_caller_tensor_like_reference():
     x = torch.zeros(2, 1, 4, 4)
     DequantizationDensity(Sink()).elbo(x)
     assert float(x.min()) >= 0 and float(x.max()) < 1 and float(x.abs().sum()) > 0
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """f4: files in the reference trainer's format (trainer.py:362-400, writer.py:105-126) written and read back; the
+    module_state_dict keys are the reference's own (golden meta), so either side can read the other's file."""
+    import math
+    from cmf_amd import checkpoint as ck
+    g, meta = load_golden("mini_mnist")
+    build = lambda: cmf_amd.get_density(cmf_amd.get_schema(cmf_amd.get_config(meta["dataset"], **meta["overrides"])), g["x"])
+    a, b = build(), build()
+    from cmf_amd.recipe import fill_state_dict
+    a.load_state_dict(fill_state_dict(a.state_dict(), seed=3))
+    opt = torch.optim.Adam([p for p in a.parameters() if p.requires_grad], lr=1e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 5)
+    path = ck.write_checkpoint(str(tmp_path), "latest", a, [opt], [sched], epoch=7, iteration=123, best_valid_loss=1.5,
+                               num_bad_valid_epochs=2)
+    assert path == str(tmp_path / "checkpoints" / "latest.pt") and not (tmp_path / "checkpoints" / "latest.pt.tmp").exists()
+    raw = torch.load(path, weights_only=False)
+    assert tuple(raw) == ck.KEYS and list(raw["module_state_dict"]) == list(meta["state_dict"])
+    opt_b = torch.optim.Adam([p for p in b.parameters() if p.requires_grad], lr=1e-3)
+    out = ck.load_checkpoint(str(tmp_path), "latest", b, [opt_b], [torch.optim.lr_scheduler.StepLR(opt_b, 5)])
+    assert (out["epoch"], out["iteration"], out["best_valid_loss"], out["num_bad_valid_epochs"]) == (7, 123, 1.5, 2)
+    for (k, v), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert k == k2 and torch.equal(v, v2), k
+    # a file whose keys lack nn.DataParallel's ``module.`` prefix (a model built the other way), and the old single-dict spelling
+    assert all(k.startswith("module.") for k in raw["module_state_dict"])
+    raw["module_state_dict"] = {k[len("module."):]: v for k, v in raw["module_state_dict"].items()}
+    raw["opt_state_dict"] = raw.pop("opt_state_dicts")[0]
+    raw["lr_scheduler_state_dict"] = raw.pop("lr_scheduler_state_dicts")[0]
+    torch.save(raw, path)
+    c = build()
+    opt_c = torch.optim.Adam([p for p in c.parameters() if p.requires_grad], lr=1e-3)
+    ck.load_checkpoint(str(tmp_path), "latest", c, [opt_c], [torch.optim.lr_scheduler.StepLR(opt_c, 5)])
+    assert all(torch.equal(v, c.state_dict()[k]) for k, v in a.state_dict().items())
+    assert math.isinf(ck.write_checkpoint.__defaults__[-2])
