@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Precision study for the hidden 3x3 tangent convolutions (CPU, dev tool): emulate operand-splitting schemes inside the
+oracle on the full-size MNIST model (fixture c3_mnist_full, B = 2, d = 64) and compare log-det / likelihood / g_ij / J with
+an fp64 evaluation.  This is how the bf16x3 scheme of conv_tangent_bf16x3.hip was chosen.
+
+  python tools/emulate_precision.py [scheme ...]      schemes: f32 bf16x1 bf16x2 bf16x3 f16x1 f16x2 f16x3
+"""
+import os, sys, time
+import torch
+import torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_golden, golden_model
+from oracle import cmf_oracle as O
+
+real_conv2d = F.conv2d
+
+
+def split(t, dt, n):
+    parts, r = [], t
+    for _ in range(n):
+        p = r.to(dt).to(torch.float32)
+        parts.append(p)
+        r = r - p
+    return parts
+
+
+def make_conv(scheme):
+    if scheme == "f32":
+        return real_conv2d
+    dt = torch.bfloat16 if scheme.startswith("bf16") else torch.float16
+    n = int(scheme[-1])
+
+    def conv(x, w, b=None, **kw):
+        if b is not None or w.shape[1] % 32 or w.shape[-1] != 3 or x.dtype != torch.float32:
+            return real_conv2d(x, w, b, **kw)                      # primal convs, first / last convs: untouched
+        # n = 1: hi*hi ; n = 2: (x_hi + x_lo) * w_hi ; n = 3: hi*hi + hi*lo + lo*hi   (fp32 accumulation)
+        xs, ws = split(x, dt, 2 if n > 1 else 1), split(w, dt, 2 if n > 2 else 1)
+        y = real_conv2d(xs[0], ws[0], None, **kw)
+        if n > 1:
+            y = y + real_conv2d(xs[1], ws[0], None, **kw)
+        if n > 2:
+            y = y + real_conv2d(xs[0], ws[1], None, **kw)
+        return y
+    return conv
+
+
+def run(scheme, ops, sd, x, noise):
+    O.F.conv2d = make_conv(scheme)
+    try:
+        t0 = time.time()
+        parts = O.elbo(sd, ops, x.clone(), add_reconstruction=True, add_offdiagonal_metric_reg=True, noise=noise, return_parts=True)
+        return parts["elbo"], parts["parts"], time.time() - t0
+    finally:
+        O.F.conv2d = real_conv2d
+
+
+def main():
+    schemes = sys.argv[1:] or ["f32", "bf16x3", "f16x1", "f16x2", "bf16x2", "bf16x1"]
+    g, meta = load_golden("c3_mnist_full")
+    _, _, _, ops, sd = golden_model(meta)
+    x, noise = g["x"], g["noise"]
+    torch.set_default_dtype(torch.float64)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    e64, p64, dt = run("f32", ops, sd64, (x + noise).double() - noise.double(), noise.double())
+    torch.set_default_dtype(torch.float32)
+    print(f"fp64 reference: {dt:.0f} s; keys {sorted(p64)}", flush=True)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300))
+    for s in schemes:
+        e, p, dt = run(s, ops, sd, x, noise)
+        out = {k: rel(p[k], p64[k]) for k in ("logdet", "likelihood", "l1", "J", "recon") if k in p and k in p64 and torch.is_tensor(p[k])}
+        print(f"{s:7s} elbo {rel(e, e64):.2e}  " + "  ".join(f"{k} {v:.2e}" for k, v in out.items()) + f"   ({dt:.0f} s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
