@@ -595,6 +595,10 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     }
     auto load_b = [&](int t) {
       const int s = t % KS, p = t / KS;
+#ifdef CMF_DBG_NOLDS                                // timing-only: no B-fragment LDS reads at all (wrong results)
+      asm volatile("" : "=v"(bh[t % BD]), "=v"(bl[t % BD]));
+      return;
+#endif
       if (s < 2) {
         bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][p & 1] + p * 256);
         bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][p & 1] + p * 256);
@@ -607,8 +611,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int c = 0; c < CW; ++c) {
+#ifdef CMF_DBG_NOA                                  // timing-only: no A-fragment reads either
+        asm volatile("" : "=v"(ah[s][c]), "=v"(al[s][c]));
+#else
         ah[s][c] = *reinterpret_cast<const bf16x8*>(Wh + (((s * COT + c) * 64) << 4) + aoff);
         al[s][c] = *reinterpret_cast<const bf16x8*>(Wl + (((s * COT + c) * 64) << 4) + aoff);
+#endif
       }
     // non-QUAD chunk: park this octet's centre pixels in ring slot `ring_slot`: the two waves of a tile row split hi / lo,
     // 14 pixel rows of 256 B = 224 sixteen-byte units per wave
