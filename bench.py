@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
                     help="arithmetic of the 3x3 tangent convolutions (both are fp32-grade; see DESIGN.md 4.5)")
+    ap.add_argument("--primal-precision", choices=["f32", "bf16x3"], default="f32",
+                    help="arithmetic of the PRIMAL hidden convs (relu masks come from these activations): f32 = exact fp32 "
+                         "products (default, parity-grade), bf16x3 = split precision, ~9 %% faster (DESIGN.md 4.2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -106,6 +109,7 @@ def main():
     from cmf_amd import engine as E
     from cmf_amd.distributed import allreduce_mean_elbo
     E.TANGENT_PRECISION = args.precision
+    E.PRIMAL_PRECISION = args.primal_precision
     cfg, schema, shape, sd, density = make_model(device)
     inner = density.module.density                       # feed dequantised data ourselves: noise is part of the synthetic input
     B = args.batch // world if args.strong else args.batch

@@ -43,7 +43,7 @@ struct Cfg {
 
 template <int TAPS, int COT, int PXW>
 __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
-                                                                int nslices, int ncog, int cin_pad) {
+                                                                int nslices, int ncog, int cin_pad, int nsub) {
   using C = Cfg<TAPS, COT, PXW>;
   __shared__ __attribute__((aligned(16))) float smem[C::XS_FLOATS + C::WS_FLOATS];
   float* Xs = smem;
@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
     cog = w % ncog;
     np = w / ncog;
   }
+  // nsub > 1: a 64-channel group is dealt to nsub workgroups of COT*16 channels each (small grids: more, lighter items)
+  const int cosub = (cog % nsub) * COT * 16;
+  cog /= nsub;
   const int HW = a.H * a.W;
 
   int y0 = 0, x0 = 0, p0 = 0;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
   const float* xb = a.x + (long long)np * a.x_np + (long long)slice * (a.x_sl ? a.x_sl : 16);
   const int fgrp = a.f_group > 1 ? a.f_group : 1;
   const float* fb = a.f ? a.f + (long long)(np / fgrp) * a.f_np + (np % fgrp) : nullptr;
-  const float* wb = a.w + (long long)cog * TAPS * cin_pad * 64;  // one co-group slab: < 2^31 floats
+  const float* wb = a.w + (long long)cog * TAPS * cin_pad * 64 + cosub;  // one co-group slab: < 2^31 floats
 
   // ---- per-thread staging plan (chunk independent part) ----
   // Every global load below is UNCONDITIONAL (invalid items read element 0 and are zeroed by their
@@ -245,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
   const int y_co = (int)a.y_co, y_px = (int)a.y_px, r_co = (int)a.r_co, r_px = (int)a.r_px;
   float* ybase = a.y + (long long)np * a.y_np + (long long)slice * (a.y_sl ? a.y_sl : 16) + cl;
   const float* rbase = a.r ? a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) + cl : nullptr;
-  const int co0 = cog * 64 + kq * 4;
-  const bool full = (cog * 64 + COT * 16) <= a.cout;   // uniform: no per-channel bound checks needed
+  const int co0 = cog * 64 + cosub + kq * 4;
+  const bool full = (cog * 64 + cosub + COT * 16) <= a.cout;   // uniform: no per-channel bound checks needed
 
   auto store_all = [&](auto has_res, auto is_full) {
 #pragma unroll
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
 }
 
 template <int TAPS, int COT, int PXW>
-int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
+int launch(const cmf_conv_tangent_args& a, hipStream_t s, int nsub = 1) {
   const int HW = a.H * a.W;
   int tiles, tiles_x = 1;
   if (TAPS == 9) {
@@ -296,18 +299,24 @@ int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   } else {
     tiles = cmf_ceil_div(HW, 4 * PXW);
   }
-  const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
+  const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64) * nsub;
   const int cin_pad = (a.cin + 7) / 8 * 8;
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
   hipLaunchKernelGGL((conv_tangent_kernel<TAPS, COT, PXW>), dim3((unsigned)total), dim3(256), 0, s, a, tiles_x, tiles,
-                     nslices, ncog, cin_pad);
+                     nslices, ncog, cin_pad, nsub);
   CMF_LAUNCH_CHECK();
   return 0;
 }
 
 template <int TAPS, int PXW>
 int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
+  // Small grids (the primal pass: 16 samples per column slot, 14 x 14 images = 224 items at B = 512 for 512 resident
+  // workgroups): deal every 64-channel group to two workgroups of 32 channels.
+  if (TAPS == 9 && a.cout % 64 == 0) {
+    const long long items = (long long)cmf_ceil_div(a.W, 2 * PXW) * cmf_ceil_div(a.H, 2) * (a.nc / 16) * (a.cout / 64) * a.np;
+    if (items < 1024) return launch<TAPS, 2, PXW>(a, s, 2);
+  }
   const int cot = (a.cout >= 64) ? 4 : (a.cout + 15) / 16;
   switch (cot) {
     case 1: return launch<TAPS, 1, PXW>(a, s);

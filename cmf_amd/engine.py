@@ -77,9 +77,21 @@ TIMER = None   # set to a KernelTimer by bench.py
 TANGENT_PRECISION = "bf16x3"
 
 
+#: arithmetic of the PRIMAL hidden 3x3 convolutions of a ResNet coupler.  They run through the tangent conv kernels with 16
+#: samples in the column slots; "f32" = the fp32-MFMA kernel (exact fp32 products), "bf16x3" = the split-precision kernel
+#: (2.5x faster, ~1e-6 relative).  The default is "f32": the relu masks of the Jacobian are taken from these activations,
+#: and a pre-activation that lands on the other side of zero than in the reference flips a mask -- with bf16x3 primals the
+#: median per-sample log-det / g_ij error against the CPU oracle was 9e-6 / 1.8e-5 instead of 3e-7 / 4e-7.
+PRIMAL_PRECISION = "f32"
+
+
 def _use_bf16x3(taps, cin, W, transpose, H=None, cout=64):
-    """Shapes the split-precision kernel is built for: whole 2 x 14 pixel tiles, whole 64- (or one 32-) channel groups."""
-    return (TANGENT_PRECISION == "bf16x3" and taps == 9 and cin % 8 == 0 and cin % 32 == 0 and (W % 14 == 0 or W % 8 == 0) and (H is None or H % 2 == 0)
+    return TANGENT_PRECISION == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
+
+
+def _shape_ok_bf16x3(taps, cin, W, transpose, H=None, cout=64):
+    """Shapes the split-precision kernel is built for: whole 2 x 14 (or 2 x 8) pixel tiles, whole 64- (or one 32-) channel groups."""
+    return (taps == 9 and cin % 8 == 0 and cin % 32 == 0 and (W % 14 == 0 or W % 8 == 0) and (H is None or H % 2 == 0)
             and (cout % 64 == 0 or cout == 32) and not transpose)
 
 
@@ -174,12 +186,13 @@ def conv_primal(x_ptr_t, x_off, x_b, x_c, x_px, weight, taps, bias, y, y_b, y_c,
 
 def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_px, np_, cin, cout, H, W, nc,
                  fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, res_t=None, transpose=False, bias=None, f_group=1,
-                 x_sl=16, y_sl=16):
+                 x_sl=16, y_sl=16, precision=None):
     lib = _lib.load()
     a = ConvTangentArgs()
     a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
     a.f = _p(f); a.f_np, a.f_ci, a.f_px = int(f_np), int(f_ci), int(f_px); a.fmode = fmode
-    split = _use_bf16x3(taps, cin, W, transpose, H, cout) and fmode != F_NONE      # the split kernel always streams a factor
+    split = ((precision or TANGENT_PRECISION) == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
+             and fmode != F_NONE)                         # the split kernel always streams a factor
     a.w = _p(PACKS.get(weight, taps, transpose, bf16x3=split))
     a.y = _p(y_t); a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
     a.r = _p(res_t); a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
@@ -377,7 +390,7 @@ def net_primal(net, z, view, need_acts=True):
         a = new(hid)
         conv_primal(z, view.chan_off * HW, geo.C * HW, view.chan_step * HW, 1, conv0.weight, 9, None, a, hid * HW, HW, 1,
                     B, view.cin, hid, H, W, imode=F_RAW if view.mask is not None else F_NONE, mask=view.mask, f_c=HW, f_px=1)
-        if B % 16 == 0 and _use_bf16x3(9, hid, W, False, H, hid):
+        if B % 16 == 0 and _shape_ok_bf16x3(9, hid, W, False, H, hid):
             return _resnet_primal_grouped(net, blocks, convf, a, B, hid, cout, H, W, need_acts)
         acts = [a]
         for blk in blocks:
@@ -425,9 +438,10 @@ def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts
     acts = [a]
     for blk in blocks:
         c1, a2 = new(), new()
-        conv_tangent(a, 0, *pn, blk.conv1.weight, 9, c1, *pn, G, hid, hid, H, W, 16, fmode=F_SELF_RELU, bias=blk.conv1.bias)
+        conv_tangent(a, 0, *pn, blk.conv1.weight, 9, c1, *pn, G, hid, hid, H, W, 16, fmode=F_SELF_RELU, bias=blk.conv1.bias,
+                     precision=PRIMAL_PRECISION)
         conv_tangent(c1, 0, *pn, blk.conv2.weight, 9, a2, *pn, G, hid, hid, H, W, 16, fmode=F_SELF_RELU, bias=blk.conv2.bias,
-                     res_t=a)
+                     res_t=a, precision=PRIMAL_PRECISION)
         acts += [c1, a2]
         a = a2
     # 1x1 + ScaledTanh on the grouped tensor: a 1x1 conv does not care that "pixels" are (pixel, sample) pairs
