@@ -13,7 +13,8 @@ def rel(a, b):
 
 @pytest.mark.parametrize("cin,cout,H,W,taps,nc", [
     (64, 64, 14, 14, 9, 64), (64, 64, 28, 28, 9, 32), (2, 64, 14, 14, 9, 16), (64, 4, 14, 14, 1, 64),
-    (64, 64, 16, 16, 9, 16), (64, 64, 32, 32, 9, 32), (3, 24, 9, 11, 9, 16), (8, 64, 14, 14, 9, 16), (16, 40, 5, 28, 9, 32), (64, 130, 3, 14, 9, 16), (17, 40, 5, 7, 9, 32), (64, 2, 28, 28, 1, 16), (130, 70, 1, 37, 1, 16),
+    (64, 64, 16, 16, 9, 16), (64, 64, 32, 32, 9, 32), (32, 64, 14, 14, 9, 16), (64, 32, 14, 28, 9, 32), (32, 32, 16, 8, 9, 16),
+    (128, 64, 14, 14, 9, 16), (96, 128, 6, 14, 9, 16), (3, 24, 9, 11, 9, 16), (8, 64, 14, 14, 9, 16), (16, 40, 5, 28, 9, 32), (64, 130, 3, 14, 9, 16), (17, 40, 5, 7, 9, 32), (64, 2, 28, 28, 1, 16), (130, 70, 1, 37, 1, 16),
 ])
 @pytest.mark.parametrize("fmode", ["none", "relu", "tanh", "raw"])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
@@ -25,7 +26,8 @@ def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, monke
     monkeypatch.setattr(E, "TANGENT_PRECISION", precision)
     if precision == "bf16x3" and (not E._use_bf16x3(taps, cin, W, False, H, cout) or fmode == "none"):
         pytest.skip("shape / mode not covered by the split-precision kernel (the engine falls back to fp32)")
-    if layout == "slice" and (cin, cout, H) not in ((64, 64, 14), (64, 64, 28), (64, 64, 32), (2, 64, 14), (64, 4, 14), (16, 40, 5)):
+    if layout == "slice" and (cin, cout, H) not in ((64, 64, 14), (64, 64, 28), (64, 64, 32), (2, 64, 14), (64, 4, 14), (16, 40, 5),
+                                                   (32, 64, 14), (64, 32, 14), (128, 64, 14), (96, 128, 6)):
         pytest.skip("slice-major layout: a subset of the shapes is enough")
     gen = torch.Generator().manual_seed(cin * 1000 + cout + H)
     B = 3
