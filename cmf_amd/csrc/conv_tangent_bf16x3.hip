@@ -141,10 +141,9 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 
   if (loader) {
     // =============================== loader waves ===============================
-    // Measured with in-kernel stamps: a loader's ~220 VALU + 14 ds_write per chunk took ~4000 cycles beside an MFMA
-    // wave on the same SIMD and set the chunk period.  VALU issue is arbitrated by priority, then age: raise the
-    // loaders (an MFMA wave needs one issue slot per 16 cycles and barely notices).
-#ifndef CMF_DBG_NOPRIO
+    // No s_setprio here: with the loaders off the critical path (scalar-VALU split, hand-counted waits) raising their
+    // priority only delays the MFMA wave of the same SIMD -- measured 1.5-3 % slower (CMF_DBG_PRIO re-enables it).
+#ifdef CMF_DBG_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
     const int lt = tid - 256;                                    // 0..255: staging item = (pixel, column quad)
