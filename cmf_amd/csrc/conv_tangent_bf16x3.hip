@@ -455,7 +455,11 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // Fragment pipeline: step t = s*PW + p consumes B fragment pair t; pairs are fetched BD-1 steps ahead into a ring
   // of BD register pairs, the A fragments of K-step s+1 are fetched at the start of K-step s into the alternate
   // set.  Everything is unrolled, so ring slots are static registers and hipcc emits counted lgkmcnt waits.
+#ifdef CMF_DBG_BD
+  constexpr int BD = CMF_DBG_BD;
+#else
   constexpr int BD = 4;
+#endif
 
   // Item context.  The launcher guarantees whole tiles (H even, W % TW == 0) and whole channel groups, so the tail has
   // NO per-pixel / per-channel validity tests, and every access is a raw buffer op: descriptor base = the item's
