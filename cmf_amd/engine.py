@@ -61,6 +61,15 @@ class KernelTimer:
     def reset(self):
         self.records = []
 
+    def by_name(self):
+        """{name: (launches, total_ms, flops, bytes)} over the recorded launches."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, fl, by, e0, e1 in self.records:
+            n, ms, f, b = out.get(name, (0, 0.0, 0.0, 0.0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1), f + fl, b + by)
+        return out
+
     def summary(self):
         torch.cuda.synchronize()
         n = len(self.records)
@@ -255,9 +264,14 @@ def acl_primal(z, y, maps, decode, lj=None):
 def acl_tangent(T, YT, z, y, g, maps):
     B = z.shape[0]
     z2, y2 = z.view(B, -1), y.view(B, -1)
-    _lib.check(_lib.load().cmf_acl_tangent(_p(T.data), T.t_b, T.t_r, _p(YT.data), YT.t_b, YT.t_r, T.nc, _p(z2),
-                                           z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]), _p(maps["si"]),
-                                           _p(maps["ti"]), maps["n"], B, _stream()), "cmf_acl_tangent")
+    launch = lambda: _lib.check(_lib.load().cmf_acl_tangent(_p(T.data), T.t_b, T.t_r, _p(YT.data), YT.t_b, YT.t_r, T.nc, _p(z2),
+                                                            z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]), _p(maps["si"]),
+                                                            _p(maps["ti"]), maps["n"], B, _stream()), "cmf_acl_tangent")
+    if TIMER is None:
+        return launch()
+    # coupling pass, per modified element: tangent rows v, s-dot, t-dot in (3 x NC floats), one row out, 5 scalars
+    n = float(maps["n"]) * B
+    TIMER.wrap("acl_tangent", 4.0 * n * T.nc, 4.0 * n * (4 * T.nc + 5), launch)
 
 
 class GramResult:
@@ -275,8 +289,13 @@ def gram_cholesky(T, d, max_attempts=6, eps0=1e-6):
     r.l1_diag = torch.empty(T.B, dtype=torch.float32, device=dev)
     r.info = torch.empty(T.B, dtype=torch.int32, device=dev)
     r.fail = torch.empty(8, dtype=torch.int32, device=dev)
-    _lib.check(lib.cmf_gram_cholesky(_p(T.data), T.t_b, T.t_r, T.N, T.nc, d, T.B, _p(r.jtj), _p(r.logdet), _p(r.l1_off),
-                                     _p(r.l1_diag), _p(r.info), _p(r.fail), _stream()), "cmf_gram_cholesky")
+    launch = lambda: _lib.check(lib.cmf_gram_cholesky(_p(T.data), T.t_b, T.t_r, T.N, T.nc, d, T.B, _p(r.jtj), _p(r.logdet),
+                                                      _p(r.l1_off), _p(r.l1_diag), _p(r.info), _p(r.fail), _stream()),
+                                "cmf_gram_cholesky")
+    if TIMER is None:
+        launch()
+    else:                                          # 2 D d^2 (+ d^3/3) FLOP and (D NC + d^2 + 3) 4 B per sample
+        TIMER.wrap("gram_cholesky", T.B * (2.0 * T.N * d * d + d ** 3 / 3.0), 4.0 * T.B * (T.N * T.nc + d * d + 3), launch)
     for a in range(1, max_attempts):
         _lib.check(lib.cmf_cholesky_retry(_p(r.jtj), d, T.B, a, eps0, _p(r.logdet), _p(r.l1_diag), _p(r.info), _p(r.fail),
                                           _stream()), "cmf_cholesky_retry")
