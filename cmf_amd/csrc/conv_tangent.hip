@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
             for (int p = 0; p < PXW; ++p)
 #pragma unroll
               for (int c = 0; c < COT; ++c)
-                acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], brow[p + dx], acc[p][c], 0, 0, 0);
+                acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(brow[p + dx], av[c], acc[p][c], 0, 0, 0);
           }
         }
       } else {
@@ -237,19 +237,25 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
           const float bv = b_base[kg * 4 * C::XS_CI + p * 16];
 #pragma unroll
           for (int c = 0; c < COT; ++c)
-            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv, acc[p][c], 0, 0, 0);
+            acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[c], acc[p][c], 0, 0, 0);
         }
       }
     }
     __syncthreads();
   }
 
-  // ---- epilogue: D[row = kq*4 + r][col = cl] of tile (p, c); offsets fit 32 bits (host-checked) ----
+  // ---- epilogue.  The MFMA operands are SWAPPED (x value as A, weight as B): D[row = Jacobian column][col = output
+  // channel], so lane (kq, cl) holds the 4 CONSECUTIVE columns kq*4 .. kq*4+3 of channel cl of tile (p, c) -> one 16-byte
+  // store / residual load per tile instead of four 4-byte ones (same products, same accumulation order, same bits).
+  // The per-channel constant is fetched once, not per store.  Offsets fit 32 bits (host-checked). ----
   const int y_co = (int)a.y_co, y_px = (int)a.y_px, r_co = (int)a.r_co, r_px = (int)a.r_px;
-  float* ybase = a.y + (long long)np * a.y_np + (long long)slice * (a.y_sl ? a.y_sl : 16) + cl;
-  const float* rbase = a.r ? a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) + cl : nullptr;
-  const int co0 = cog * 64 + cosub + kq * 4;
+  float* ybase = a.y + (long long)np * a.y_np + (long long)slice * (a.y_sl ? a.y_sl : 16) + kq * 4;
+  const float* rbase = a.r ? a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) + kq * 4 : nullptr;
+  const int co0 = cog * 64 + cosub + cl;
   const bool full = (cog * 64 + cosub + COT * 16) <= a.cout;   // uniform: no per-channel bound checks needed
+  float bias[COT];
+#pragma unroll
+  for (int c = 0; c < COT; ++c) bias[c] = (a.bias && (full || co0 + c * 16 < a.cout)) ? a.bias[co0 + c * 16] : 0.f;
 
   auto store_all = [&](auto has_res, auto is_full) {
 #pragma unroll
@@ -268,16 +274,13 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
       float* yp = ybase + gpix * y_px + co0 * y_co;
       const float* rp = has_res ? rbase + gpix * r_px + co0 * r_co : nullptr;
 #pragma unroll
-      for (int c = 0; c < COT; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (is_full || (co0 + c * 16 + r) < a.cout) {
-            float v = acc[p][c][r];
-            if (a.bias) v += a.bias[co0 + c * 16 + r];
-            if (has_res) v += rp[(c * 16 + r) * r_co];
-            yp[(c * 16 + r) * y_co] = v;
-          }
+      for (int c = 0; c < COT; ++c) {
+        if (is_full || (co0 + c * 16) < a.cout) {
+          f32x4 v = acc[p][c] + bias[c];
+          if (has_res) v += *reinterpret_cast<const f32x4*>(rp + (c * 16) * r_co);
+          *reinterpret_cast<f32x4*>(yp + (c * 16) * y_co) = v;
         }
+      }
     }
   };
   if (rbase) {
@@ -340,6 +343,8 @@ extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
   if (a.fmode != CMF_F_NONE && a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
   // 16-byte vector loads of the column slices
   if ((a.x_np | a.x_ci | a.x_px | a.x_sl | a.y_sl | a.r_sl) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
+  if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;            // 16-byte stores
+  if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;    // 16-byte residual loads
   const long long HW = (long long)a.H * a.W;
   // per-sample offsets are held in 32-bit registers
   if (!fits_int((a.cin + 8) * a.x_ci + HW * a.x_px + a.nc) || !fits_int((a.cin + 8) * a.f_ci + HW * a.f_px) ||
