@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
 
 #pragma unroll
     for (int kg = 0; kg < CIC / 4; ++kg) {
+      if (ch * CIC + kg * 4 >= a.cin) break;              // all-padding K group (the 1 -> 64 / 2 -> 64 first convs): skip
       if (TAPS == 9) {
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
