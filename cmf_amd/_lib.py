@@ -24,7 +24,8 @@ class ConvTangentArgs(C.Structure):
                 ("y", _fp), ("y_np", _ll), ("y_co", _ll), ("y_px", _ll),
                 ("r", _fp), ("r_np", _ll), ("r_co", _ll), ("r_px", _ll),
                 ("np", _i), ("cin", _i), ("cout", _i), ("H", _i), ("W", _i), ("nc", _i), ("taps", _i),
-                ("bias", _fp), ("f_group", _i), ("x_sl", _ll), ("y_sl", _ll), ("r_sl", _ll)]
+                ("bias", _fp), ("f_group", _i), ("x_sl", _ll), ("y_sl", _ll), ("r_sl", _ll),
+                ("fo", _fp), ("fo_np", _ll), ("fo_co", _ll), ("fo_px", _ll), ("fomode", _i)]
 
 
 class ConvPrimalArgs(C.Structure):
@@ -49,6 +50,7 @@ SIGNATURES = {
     "cmf_conv_primal": (_i, [C.POINTER(ConvPrimalArgs), _fp]),
     "cmf_acl_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "cmf_acl_tangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _fp]),
+    "cmf_acl_cotangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _fp]),
     "cmf_gather_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _i, _i, _fp]),
     "cmf_gather_tangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _fp, _i, _i, _i, _fp]),
     "cmf_seed_tangent": (_i, [_fp, _ll, _ll, _fp, _i, _i, _fp, _i, _i, _i, _fp]),

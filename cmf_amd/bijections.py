@@ -139,6 +139,23 @@ class AffineCouplingBijection(Bijection):
             E.acl_tangent(T, YT, z, y, g, self.maps(z.device))      # uses z BEFORE the primal update
         E.acl_primal(z, y, self.maps(z.device), decode=True, lj=lj)
 
+    # reverse sweep (J^T w): primal decode that keeps what the adjoint needs, then the adjoint step ------------
+    def decode_ctx_(self, z):
+        view = self.view(z.device)
+        zb = z.clone()
+        y, g, acts = E.net_primal(self.net, z, view, need_acts=True)
+        E.acl_primal(z, y, self.maps(z.device), decode=True)
+        return zb, y, g, acts
+
+    def decode_vjp_(self, Ct, ctx):
+        """Adjoint of the tangent update of ``decode_`` on the cotangent stack ``Ct`` (in place)."""
+        zb, y, g, acts = ctx
+        dev = zb.device
+        YC = E.Tangent(Ct.B, y[0].numel(), Ct.nc, self.layout, dev)
+        YC.data.zero_()
+        E.acl_cotangent(Ct, YC, zb, y, g, self.maps(dev))
+        E.net_cotangent(self.net, YC, self.view(dev), acts, Ct)
+
     # protocol ------------------------------------------------------------------------------------
     def _x_to_z(self, x):
         E.require_gpu(x)
@@ -242,6 +259,10 @@ class _ReshapingBijection(Bijection):
             T = E.gather_tangent(T, self._maps.get("z2x", z.device), self.n)
         return x, T
 
+    def decode_vjp(self, Ct):
+        """Adjoint of ``decode`` on a cotangent stack: the inverse index map."""
+        return E.gather_tangent(Ct, self._maps.get("x2z", Ct.data.device), self.n)
+
     def _zeros(self, t):
         return torch.zeros(t.shape[0], 1, dtype=t.dtype, device=t.device)
 
@@ -270,6 +291,9 @@ class ViewBijection(_ReshapingBijection):
 
     def decode(self, z, T=None):
         return z.view(z.shape[0], *self.x_shape), T
+
+    def decode_vjp(self, Ct):
+        return Ct
 
 
 class Squeeze2dBijection(_ReshapingBijection):

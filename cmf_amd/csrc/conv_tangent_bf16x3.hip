@@ -800,6 +800,7 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   if (a.fmode <= CMF_F_NONE || a.fmode > CMF_F_SELF_RELU) return CMF_EINVAL;   // NONE: use cmf_conv_tangent (the loader's
                                                                               // load schedule always carries a factor stream)
   if (a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
+  if (a.fo) return CMF_EINVAL;                                  // output-side factors: cmf_conv_tangent only
   if ((a.x_np | a.x_ci | a.x_px | a.x_sl | a.y_sl | a.r_sl) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
   if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;            // 16-byte stores
   if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;    // 16-byte residual loads

@@ -83,6 +83,29 @@ __global__ void acl_tangent_kernel(float* __restrict__ t, long long t_b, long lo
   *tp = es * (v - (zo * gs) * sd) - gt * td;
 }
 
+// acl cotangent (adjoint of acl_tangent_kernel): flat over (b, e, col4)
+__global__ void acl_cotangent_kernel(float* __restrict__ c, long long c_b, long long c_r, float* __restrict__ yc,
+                                     long long yc_b, long long yc_r, int nc4, const float* __restrict__ z, long long z_b,
+                                     const float* __restrict__ y, long long y_b, const float* __restrict__ g,
+                                     const int* __restrict__ zi, const int* __restrict__ si, const int* __restrict__ ti,
+                                     int n_mod, long long total) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const int c4 = (int)(i % nc4);
+  const long long be = i / nc4;
+  const int e = (int)(be % n_mod);
+  const long long b = be / n_mod;
+  const int rs = si[e], rt = ti[e], rz = zi[e];
+  const float s = y[b * y_b + rs], zo = z[b * z_b + rz];
+  const float gs = g ? g[b * y_b + rs] : 1.f, gt = g ? g[b * y_b + rt] : 1.f;
+  const float es = expf(-s);
+  f32x4* cp = reinterpret_cast<f32x4*>(c + b * c_b + (long long)rz * c_r) + c4;
+  const f32x4 v = *cp;
+  reinterpret_cast<f32x4*>(yc + b * yc_b + (long long)rt * yc_r)[c4] = (-gt) * v;
+  reinterpret_cast<f32x4*>(yc + b * yc_b + (long long)rs * yc_r)[c4] = (-(es * zo * gs)) * v;
+  *cp = es * v;
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void gather_primal_kernel(const float* __restrict__ in, long long in_b, float* __restrict__ out,
                                      long long out_b, const int* __restrict__ idx, int n_out, long long total) {
@@ -280,6 +303,18 @@ int cmf_acl_tangent(float* t, long long t_b, long long t_r, const float* yt, lon
   const long long total = (long long)B * n_mod * (nc / 4);
   hipLaunchKernelGGL(acl_tangent_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, t, t_b, t_r, yt, yt_b,
                      yt_r, nc / 4, z, z_b, y, y_b, g, zi, si, ti, n_mod, total);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+int cmf_acl_cotangent(float* c, long long c_b, long long c_r, float* yc, long long yc_b, long long yc_r, int nc,
+                      const float* z, long long z_b, const float* y, long long y_b, const float* g, const int* zi,
+                      const int* si, const int* ti, int n_mod, int B, void* stream) {
+  if (!c || !yc || !z || !y || !zi || !si || !ti || n_mod <= 0 || B <= 0 || nc <= 0 || nc % 4) return CMF_EINVAL;
+  if ((c_b | c_r | yc_b | yc_r) % 4 || (uintptr_t)c % 16 || (uintptr_t)yc % 16) return CMF_EINVAL;
+  const long long total = (long long)B * n_mod * (nc / 4);
+  hipLaunchKernelGGL(acl_cotangent_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, c, c_b, c_r, yc, yc_b,
+                     yc_r, nc / 4, z, z_b, y, y_b, g, zi, si, ti, n_mod, total);
   CMF_LAUNCH_CHECK();
   return 0;
 }

@@ -366,6 +366,40 @@ class FlowProgram:
                 z, T = m.decode(z, T)
         return z, T
 
+    # -- reverse sweep: cotangents in data space -> J^T w in latent space ---------------------------
+    def vjp(self, z_low, Wd):
+        """``Wd``: (B, D, S) cotangent columns over the flattened data space; returns (x_hat, J^T Wd) with J^T Wd of shape
+        (B, d, S) -- the vjp of ``flow_forward`` (non_square.py:190-201) for S directions at once.  A primal decode keeps
+        each coupling layer's state, then the layers' adjoints run in encode order; transposed convolutions use the fp32
+        MFMA kernel (``engine.net_cotangent``)."""
+        B, dev = z_low.shape[0], z_low.device
+        N = int(np.prod(self.tail.x_shape))
+        z = E.gather_primal(z_low.contiguous(), self.tail.scatter_index(dev), N).view(B, *self.tail.x_shape)
+        ctx = []
+        for m in reversed(self.layers):
+            if isinstance(m, AffineCouplingBijection):
+                ctx.append(m.decode_ctx_(z))
+            elif isinstance(m, SplitDensity):
+                n = z[0].numel()
+                idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),
+                                 torch.full((n,), -1, dtype=torch.int32, device=dev)))
+                z = E.gather_primal(z, idx, 2 * n).view(B, 2 * z.shape[1], *z.shape[2:])
+                ctx.append(n)
+            else:
+                z, _ = m.decode(z, None)
+                ctx.append(None)
+        S = Wd.shape[2]
+        Ct = E.Tangent.from_dense(Wd.contiguous().float(), E.ceil16(S), self.layout)
+        for m, c in zip(self.layers, reversed(ctx)):
+            if isinstance(m, AffineCouplingBijection):
+                m.decode_vjp_(Ct, c)
+            elif isinstance(m, SplitDensity):                      # adjoint of the zero-padding: keep the first half
+                Ct = E.gather_tangent(Ct, torch.arange(c, dtype=torch.int32, device=dev), c)
+            else:
+                Ct = m.decode_vjp(Ct)
+        out = E.gather_tangent(Ct, self.tail.gather_index(dev), self.d)
+        return z, out.to_dense(S).contiguous()
+
     # -- latent noise -> z_low (sampling) ----------------------------------------------------------
     def prior_inverse(self, u):
         z = u.detach().clone().contiguous()
@@ -581,6 +615,19 @@ class NonSquareHeadDensity(Density):
         """One tangent direction v (B, d): returns (x_hat, J v) like non_square.py:322-329."""
         x_hat, T = self.program.decode(z_low, tangents=True, eps=v.reshape(*v.shape, 1).contiguous())
         return x_hat, T.to_dense(1)[:, :, 0].reshape(x_hat.shape)
+
+    def vjp_forward(self, z_low, w):
+        """One cotangent direction w (B, *x_shape): returns (x_hat, J^T w) with J^T w of shape (B, d) -- the reverse-mode
+        counterpart of ``jvp_forward`` (the reference gets it from autograd, non_square.py:190-201)."""
+        x_hat, out = self.program.vjp(z_low, w.reshape(w.shape[0], -1, 1))
+        return x_hat, out[:, :, 0]
+
+    def jtj_matvec(self, z_low, v):
+        """Matrix-free (J^T J) v for v (B, d, S): one JVP sweep and one VJP sweep (non_square.py:190-201)."""
+        x_hat, T = self.program.decode(z_low, tangents=True, eps=v.contiguous())
+        S = v.shape[2]
+        _, out = self.program.vjp(z_low, T.to_dense(S))
+        return x_hat, out
 
     def jacobian(self, z_low):
         """Dense J (B, D, d) -- the tensor the reference stacks at non_square.py:307."""

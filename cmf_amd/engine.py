@@ -124,6 +124,18 @@ class Tangent:
     def like(self, N):
         return Tangent(self.B, N, self.nc, self.layout, self.data.device)
 
+    @staticmethod
+    def from_dense(dense, nc, layout):
+        """(B, N, S) torch tensor -> tangent / cotangent stack with S <= nc columns (the rest zero)."""
+        B, N, S = dense.shape
+        t = Tangent(B, N, nc, layout, dense.device)
+        buf = t.data[: B * N * nc].zero_()
+        if layout == "panel":
+            buf.view(B, N, nc)[:, :, :S] = dense
+        else:
+            buf.view(N, B, nc)[:, :, :S] = dense.permute(1, 0, 2)
+        return t
+
     def to_dense(self, ncols):
         """(B, N, ncols) torch view/copy for tests and the public jvp API."""
         if self.layout == "panel":
@@ -195,16 +207,20 @@ def conv_primal(x_ptr_t, x_off, x_b, x_c, x_px, weight, taps, bias, y, y_b, y_c,
 
 def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_px, np_, cin, cout, H, W, nc,
                  fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, res_t=None, transpose=False, bias=None, f_group=1,
-                 x_sl=16, y_sl=16, precision=None):
+                 x_sl=16, y_sl=16, precision=None, y_off=0, res_off=0, fo=None, fo_np=0, fo_co=0, fo_px=0, fomode=F_NONE):
+    """``fo`` = OUTPUT-side factor (reverse sweep, fp32 kernel only); ``y_off`` / ``res_off`` = element offsets into
+    ``y_t`` / ``res_t`` (in-place accumulation into a strided view of a larger tensor)."""
     lib = _lib.load()
     a = ConvTangentArgs()
     a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
     a.f = _p(f); a.f_np, a.f_ci, a.f_px = int(f_np), int(f_ci), int(f_px); a.fmode = fmode
     split = ((precision or TANGENT_PRECISION) == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
-             and fmode != F_NONE)                         # the split kernel always streams a factor
+             and fmode != F_NONE and fo is None)          # the split kernel always streams a factor; no output factor
     a.w = _p(PACKS.get(weight, taps, transpose, bf16x3=split))
-    a.y = _p(y_t); a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
-    a.r = _p(res_t); a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
+    a.y = C.c_void_p(y_t.data_ptr() + 4 * int(y_off)); a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
+    a.r = None if res_t is None else C.c_void_p(res_t.data_ptr() + 4 * int(res_off))
+    a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
+    a.fo = _p(fo); a.fo_np, a.fo_co, a.fo_px, a.fomode = int(fo_np), int(fo_co), int(fo_px), int(fomode)
     a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), int(taps)
     a.bias = _p(bias); a.f_group = int(f_group)
     a.x_sl, a.y_sl, a.r_sl = int(x_sl), int(y_sl), int(y_sl)
@@ -272,6 +288,16 @@ def acl_tangent(T, YT, z, y, g, maps):
     # coupling pass, per modified element: tangent rows v, s-dot, t-dot in (3 x NC floats), one row out, 5 scalars
     n = float(maps["n"]) * B
     TIMER.wrap("acl_tangent", 4.0 * n * T.nc, 4.0 * n * (4 * T.nc + 5), launch)
+
+
+def acl_cotangent(Ct, YC, z, y, g, maps):
+    """Adjoint of acl_tangent on the cotangent tensor ``Ct`` (in place on the modified rows); fills the modified rows of
+    ``YC`` (cotangent of the coupler network's raw output; the caller zeroed it)."""
+    B = z.shape[0]
+    z2, y2 = z.view(B, -1), y.view(B, -1)
+    _lib.check(_lib.load().cmf_acl_cotangent(_p(Ct.data), Ct.t_b, Ct.t_r, _p(YC.data), YC.t_b, YC.t_r, Ct.nc, _p(z2),
+                                             z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]), _p(maps["si"]),
+                                             _p(maps["ti"]), maps["n"], B, _stream()), "cmf_acl_cotangent")
 
 
 class GramResult:
@@ -524,3 +550,55 @@ def net_tangent(net, T, view, acts, transpose_packs=False):
             fmode, f, f_px = F_TANH, acts[i], lin.out_features
         x_t, x_off, x_ci, cin = out.data, 0, B * nc, lin.out_features
     return out
+
+
+def net_cotangent(net, YC, view, acts, Ct):
+    """Reverse sweep through the coupler network (the adjoint of ``net_tangent``): ``YC`` is the cotangent of the network's
+    raw output; the cotangent of its input is ACCUMULATED into the rows of ``Ct`` the network reads (``view``).
+    The adjoint of "factor, then conv" is "transposed conv, then factor": transposed / tap-flipped packs
+    (``cmf_pack_weight(transpose=1)``) and the OUTPUT-side factor of ``cmf_conv_tangent`` (fp32 MFMA kernel)."""
+    geo, B, nc, dev = view.geom, Ct.B, Ct.nc, Ct.data.device
+    f32 = dict(transpose=True, precision="f32")
+    if net.kind == "resnet":
+        conv0, blocks, convf = _resnet_parts(net)
+        hid, cout, H, W, HW = conv0.out_channels, convf.out_channels, geo.H, geo.W, geo.HW
+        assert getattr(acts, "f_group", 1) == 1, "the reverse sweep reads per-sample activations"
+        new = lambda c: Tangent(B, c * HW, nc, "panel", dev)
+        pn = lambda c: (c * HW * nc, HW * nc, nc)          # (np, chan, px) strides of a panel with c channels
+        fa = dict(fo_np=hid * HW, fo_co=HW, fo_px=1, fomode=F_RELU)
+        # y = convf(relu'(a_last) . h)  ->  c_h = relu'(a_last) . convf^T(c_y)
+        ch = new(hid)
+        conv_tangent(YC.data, 0, *pn(cout), convf.weight, 1, ch.data, *pn(hid), B, cout, hid, H, W, nc, fo=acts[-1], **fa, **f32)
+        u, ch2 = new(hid), new(hid)
+        for k in reversed(range(len(blocks))):
+            blk, a_in, c1 = blocks[k], acts[2 * k], acts[2 * k + 1]
+            # h2 = h + conv2(relu'(c1) . conv1(relu'(a_in) . h))  ->  c_h = c_h2 + relu'(a_in) . conv1^T(relu'(c1) . conv2^T(c_h2))
+            conv_tangent(ch.data, 0, *pn(hid), blk.conv2.weight, 9, u.data, *pn(hid), B, hid, hid, H, W, nc, **f32)
+            conv_tangent(u.data, 0, *pn(hid), blk.conv1.weight, 9, ch2.data, *pn(hid), B, hid, hid, H, W, nc, fmode=F_RELU, f=c1,
+                         f_np=hid * HW, f_ci=HW, f_px=1, res_t=ch.data, fo=a_in, **fa, **f32)
+            ch, ch2 = ch2, ch
+        # h0 = conv0(mask . v_in)  ->  Ct[view] += mask . conv0^T(c_h0)
+        off = view.chan_off * HW * nc
+        m = view.mask
+        conv_tangent(ch.data, 0, *pn(hid), conv0.weight, 9, Ct.data, Ct.t_b, view.chan_step * HW * nc, nc, B, hid, view.cin, H, W, nc,
+                     y_off=off, res_t=Ct.data, res_off=off, fo=m, fo_np=0, fo_co=HW, fo_px=1,
+                     fomode=F_RAW if m is not None else F_NONE, **f32)
+        return
+    lins = [mod for mod in net if isinstance(mod, nn.Linear)]
+    # x_i = W_i (phi_{i-1} . x_{i-1}), phi_0 = 1, phi_i = tanh'(h_i):  c~_{i-1} = W_i^T (phi_i . c~_i) with the factor on the
+    # INPUT side of the next transposed layer; the chain ends unmasked, accumulated into the rows the network read
+    x_t, x_ci, cin = YC.data, B * nc, lins[-1].out_features
+    for i in reversed(range(len(lins))):
+        lin = lins[i]
+        last = i == 0
+        fmode, f, f_px = (F_TANH, acts[i], lin.out_features) if i < len(acts) and i < len(lins) - 1 else (F_NONE, None, 0)
+        if last:
+            off = view.chan_off * B * nc
+            conv_tangent(x_t, 0, 0, x_ci, nc, lin.weight, 1, Ct.data, 0, view.chan_step * B * nc, nc, 1, cin, view.cin, 1, B, nc,
+                         fmode=fmode, f=f, f_np=0, f_ci=1, f_px=f_px, y_off=off, res_t=Ct.data, res_off=off, **f32)
+        else:
+            out = Tangent(B, lin.in_features, nc, "fmajor", dev)
+            conv_tangent(x_t, 0, 0, x_ci, nc, lin.weight, 1, out.data, 0, B * nc, nc, 1, cin, lin.in_features, 1, B, nc,
+                         fmode=fmode, f=f, f_np=0, f_ci=1, f_px=f_px, **f32)
+            x_t, cin = out.data, lin.in_features
+

@@ -78,6 +78,12 @@ typedef struct {
                                                    contiguous columns.  The slice-major hidden layout
                                                    [pixel][slice][channel][16] (x_px = C*nc, x_sl = C*16, x_ci = 16)
                                                    makes a wave's 16 channels x 16 columns one contiguous KiB        */
+  const float* fo; long long fo_np, fo_co, fo_px; int fomode;
+                                                /* OUTPUT-side factor (cmf_conv_tangent only; the split kernel rejects
+                                                   it): y = Fo(np, co, px) * conv(F * x) + bias + r, Fo derived from fo
+                                                   by fomode like F from f (NONE / RELU / TANH / RAW).  This is what the
+                                                   reverse (cotangent) sweep needs: the adjoint of "mask, then conv" is
+                                                   "transposed conv, then mask" (weights from cmf_pack_weight(transpose=1)) */
 } cmf_conv_tangent_args;
 int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
 
@@ -130,6 +136,12 @@ int cmf_acl_primal(float* z, long long z_b, const float* y, long long y_b, const
 /* tangent: T(b, zi[e], :) = exp(-s) * (T(b, zi[e], :) - z_old * sdot) - tdot   (acl.py:61-64, :137-144)
  *   sdot = gs * yt(b, si[e], :), tdot = gt * yt(b, ti[e], :), gs/gt = g(b, si[e]) / g(b, ti[e]) or 1 when
  *   g == NULL; z_old = z(b, zi[e]) BEFORE cmf_acl_primal decode is applied; s from y.              */
+/* cotangent (adjoint of cmf_acl_tangent, for J^T w / the reverse sweep): with c = C(b, zi[e], :) on entry,
+ *   yc(b, ti[e], :) = -gt * c,   yc(b, si[e], :) = -(exp(-s) * z_old * gs) * c,   C(b, zi[e], :) = exp(-s) * c.
+ * yc rows that no element maps to must be zero (the caller clears yc).                              */
+int cmf_acl_cotangent(float* c, long long c_b, long long c_r, float* yc, long long yc_b, long long yc_r, int nc,
+                      const float* z, long long z_b, const float* y, long long y_b, const float* g, const int* zi,
+                      const int* si, const int* ti, int n_mod, int B, void* stream);
 int cmf_acl_tangent(float* t, long long t_b, long long t_r, const float* yt, long long yt_b, long long yt_r,
                     int nc, const float* z, long long z_b, const float* y, long long y_b, const float* g,
                     const int* zi, const int* si, const int* ti, int n_mod, int B, void* stream);

@@ -348,3 +348,32 @@ def test_bench_contract_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_reverse_sweep_vjp_and_matrix_free_jtj(name):
+    """J^T w from the reverse sweep (transposed convs + ACL adjoints) equals the dense Jacobian applied to w, and the
+    matrix-free (J^T J) v of non_square.py:190-201 equals the Gram matrix of the exact path applied to v; its value is
+    also pinned by the reference vector JtJ.eps of the fixture (hutch_jtj_eps) where present."""
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    z = g["z_low"].cuda()
+    B, d = z.shape
+    gen = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        x_hat, J = head.jacobian(z)                                   # (B, D, d)
+        D = J.shape[1]
+        w = torch.randn(B, D, 3, generator=gen).cuda()
+        xh2, got = head.program.vjp(z, w)
+        want = torch.einsum("bnd,bns->bds", J.double(), w.double())
+        assert rel(xh2, x_hat) < 1e-6
+        assert rel(got, want) < 2e-5
+        _, one = head.vjp_forward(z, w[:, :, 0].reshape(B, *x_hat.shape[1:]))
+        assert rel(one, want[:, :, 0]) < 2e-5
+        v = torch.randn(B, d, 2, generator=gen).cuda()
+        _, mv = head.jtj_matvec(z, v)
+        G = torch.einsum("bni,bnj->bij", J.double(), J.double())
+        assert rel(mv, torch.einsum("bij,bjs->bis", G, v.double())) < 2e-5
+        if "hutch_eps" in g and "hutch_jtj_eps" in g:
+            _, ref_mv = head.jtj_matvec(z, g["hutch_eps"].cuda())
+            assert rel(ref_mv, g["hutch_jtj_eps"]) < 1e-4
