@@ -10,7 +10,7 @@ over xGMI.  ``torch.distributed`` with backend "nccl" is RCCL on ROCm; CPU tests
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_batch", "broadcast_state", "allreduce_mean_elbo"]
+__all__ = ["shard_batch", "broadcast_state", "allreduce_mean_elbo", "allreduce_gradients"]
 
 
 def _active():
@@ -42,3 +42,41 @@ def allreduce_mean_elbo(elbo):
     if _active():
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     return acc[0] / acc[1]
+
+
+def allreduce_gradients(parameters, bucket_bytes=64 << 20, average=True):
+    """Data-parallel gradient reduction for the one-process-per-GPU trainer: the ``.grad`` tensors are packed
+    into a few large flat buckets (the MNIST model's 5.98 M fp32 gradients = 24 MB are ONE bucket) and all-reduced over
+    RCCL / xGMI -- the point-to-point links favour few, large collectives over a per-parameter loop.  ``nn.DataParallel``
+    in the reference does the equivalent reduce-to-device-0 inside its backward (``wrapper.py:52-68``).  In place; a
+    parameter without a gradient on this rank contributes zeros (every rank must call with the same parameter list)."""
+    params = [p for p in parameters if p.requires_grad]
+    if not params:
+        return 0
+    world = dist.get_world_size() if _active() else 1
+    buckets, cur, size = [], [], 0
+    for p in params:
+        n = p.numel() * 4
+        if cur and size + n > bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(p)
+        size += n
+    buckets.append(cur)
+    for group in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in group])
+        if _active():
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if average:
+                flat /= world
+        off = 0
+        for p in group:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+    return len(buckets)
+

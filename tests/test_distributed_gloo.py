@@ -71,3 +71,52 @@ def test_shard_batch_partitions_unevenly_divisible_batches():
     assert [p.shape[0] for p in parts] == [3, 3, 3, 2]
     assert torch.equal(torch.cat(parts), x)
     assert shard_batch(x).shape[0] == 11                                 # no process group: identity
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cmf_amd.distributed import allreduce_gradients
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+        frozen = torch.nn.Parameter(torch.ones(4), requires_grad=False)
+        x = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10
+        mine = x[rank * 4:(rank + 1) * 4]
+        net(mine).pow(2).sum().backward()
+        if rank == 1:
+            net[2].bias.grad = None                  # a parameter without a gradient on one rank
+        nb = allreduce_gradients(list(net.parameters()) + [frozen], bucket_bytes=64)     # tiny buckets: several of them
+        q.put((rank, nb, [p.grad.clone() for p in net.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_gradients_matches_full_batch():
+    """world_size 2, gloo: bucketed gradient all-reduce (sum / world) == the two shards' gradients averaged."""
+    world, port = 2, 29537
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+    x = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10
+    g = []
+    for r in range(2):
+        net.zero_grad()
+        net(x[r * 4:(r + 1) * 4]).pow(2).sum().backward()
+        g.append([p.grad.clone() for p in net.parameters()])
+    g[1][3] = torch.zeros_like(g[1][3])              # rank 1 dropped its last-bias gradient
+    want = [(a + b) / 2 for a, b in zip(*g)]
+    assert res[0][1] == res[1][1] and res[0][1] > 1
+    for r in range(2):
+        for got, w in zip(res[r][2], want):
+            assert torch.allclose(got, w, rtol=1e-6, atol=1e-7)
+
