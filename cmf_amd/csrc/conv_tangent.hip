@@ -322,8 +322,10 @@ template <int TAPS, int PXW>
 int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
   // Small grids (the primal pass: 16 samples per column slot, 14 x 14 images = 224 items at B = 512 for 512 resident
   // workgroups): deal every 64-channel group to two workgroups of 32 channels.
-  if (TAPS == 9 && a.cout % 64 == 0) {
-    const long long items = (long long)cmf_ceil_div(a.W, 2 * PXW) * cmf_ceil_div(a.H, 2) * (a.nc / 16) * (a.cout / 64) * a.np;
+  if (a.cout % 64 == 0) {
+    const long long tiles = TAPS == 9 ? (long long)cmf_ceil_div(a.W, 2 * PXW) * cmf_ceil_div(a.H, 2)
+                                      : (long long)cmf_ceil_div(a.H * a.W, 4 * PXW);
+    const long long items = tiles * (a.nc / 16) * (a.cout / 64) * a.np;
     if (items < 1024) return launch<TAPS, 2, PXW>(a, s, 2);
   }
   const int cot = (a.cout >= 64) ? 4 : (a.cout + 15) / 16;
