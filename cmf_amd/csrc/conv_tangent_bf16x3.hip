@@ -50,12 +50,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int COT, int PXW>
 struct BCfg {
-  static constexpr int TW = 2 * PXW, TWH = TW + 2, PIXH = 4 * TWH;
+  // tile = TH rows x TW pixels: 2 x 14 for 14- / 28-wide images (PXW = 7), 4 x 8 for 16- / 32-wide ones (PXW = 4: 60 halo
+  // pixels = 240 staging items, halo overhead 1.9x); an MFMA wave owns RW = TH/2 rows = PW pixels
+  static constexpr int TH = PXW == 4 ? 4 : 2, RW = TH / 2, TW = 2 * PXW, PW = RW * TW, TWH = TW + 2, PIXH = (TH + 2) * TWH;
+  // LDS pixel index of the wave's pixel p relative to its pixel 0 (rows are TWH apart in the halo image)
+  static constexpr int pl(int p) { return (p / TW) * TWH + p % TW; }
   static constexpr int XS_BYTES = PIXH * 16 * 16;                 // one of hi / lo
   static constexpr int WS_BYTES = 3 * COT * 4 * 16 * 16;          // one of hi / lo
   static constexpr int BUF_BYTES = 2 * XS_BYTES + 2 * WS_BYTES;   // one pipeline stage
   // centre ring: the tile's own pixels (no halo) of three octets, hi and lo, for the 4-octet centre-tap K-step
-  static constexpr int RING_HALF = 2 * TW * 16 * 16;               // one of hi / lo of one octet: 2 rows x TW pixels x 256 B
+  static constexpr int RING_HALF = TH * TW * 16 * 16;              // one of hi / lo of one octet: TH rows x TW pixels x 256 B
   static constexpr int RING_SLOT = 2 * RING_HALF;
   static constexpr int LDS_BYTES = 2 * BUF_BYTES + 3 * RING_SLOT;
   static constexpr int W_CHUNK_BYTES = 2 * 3 * 4 * 4 * 16 * 16;   // global: [hl][s][cot 4][kq][co][8] bf16 = 24 KiB
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // a SIMD with.
   constexpr bool SELF = MODE == 2, RELU = MODE == 1;
   using C = BCfg<COT, PXW>;
-  constexpr int CW = COT / 2, PW = 2 * PXW;
+  constexpr int CW = COT / 2, PW = C::PW;
   static_assert(COT % 2 == 0, "the co-split wave layout needs an even number of output-channel tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages x [Xh | Xl | Wh | Wl]
 
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     auto set_item = [&](int item) {
       int tile, slice, cog, np;
       decode(item, tile, slice, cog, np);
-      const int y0 = 2 * (tile / tiles_x), x0 = C::TW * (tile % tiles_x);
+      const int y0 = C::TH * (tile / tiles_x), x0 = C::TW * (tile % tiles_x);
       xrs = make_rsrc(a.x + (long long)np * a.x_np + (long long)slice * (a.x_sl ? a.x_sl : 16));
       frs = make_rsrc(a.f ? a.f + (long long)(np / fgrp) * a.f_np + (np % fgrp) : a.x);
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #ifdef CMF_DBG_MFMAPRIO
   __builtin_amdgcn_s_setprio(3);
 #endif
-  const int wrow = wave >> 1, cohalf = wave & 1;
+  const int wrow = C::RW * (wave >> 1), cohalf = wave & 1;        // first tile row of this wave
   const int y_co = (int)a.y_co, y_px = (int)a.y_px, r_co = (int)a.r_co, r_px = (int)a.r_px;
 
   // Per-lane B offsets: lane group kq of K-step s reads tap 4*s + kq (taps >= 9 read tap 8's data against zero
@@ -443,6 +447,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // centre K-step: per-lane source (ring slot kq for kq < 3, the live stage for kq == 3), relative to smem.  Ring rows
   // are verbatim copies of the stage's pixel rows, so the slot permutation is the stage's (parity of the halo pixel).
   const int cpix = (wrow + 1) * C::TWH + 1;                        // halo index of this wave's pixel p = 0
+  const int crow = kq < 3 ? 0 : (C::TWH - C::TW) * 256;            // extra bytes per tile row for the lanes that read the stage
   int coff_ring[2], coff_stage[2];
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #ifdef CMF_DBG_BD
   constexpr int BD = CMF_DBG_BD;
 #else
-  constexpr int BD = 4;
+  constexpr int BD = C::PW > 14 ? 3 : 4;                           // 16-pixel waves (4 x 8 tiles): 128 accumulator VGPRs, shallower ring
 #endif
 
   // Item context.  The launcher guarantees whole tiles (H even, W % TW == 0) and whole channel groups, so the tail has
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   auto item_geom = [&](int item, int& np, int& slice, int& cog, Item& it) {
     int tile;
     decode(item, tile, slice, cog, np);
-    const int pix0 = (2 * (tile / tiles_x) + wrow) * a.W + C::TW * (tile % tiles_x);
+    const int pix0 = (C::TH * (tile / tiles_x) + wrow) * a.W + C::TW * (tile % tiles_x);
     it.ypix = 4 * pix0 * y_px;
     it.rpix = 4 * pix0 * r_px;
   };
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #endif
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-      const int so = it.rpix + 4 * (p * r_px + c * 16 * r_co);
+      const int so = it.rpix + 4 * (((p / C::TW) * a.W + p % C::TW) * r_px + c * 16 * r_co);
       asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(acc[p][c]) : "v"(rvoff), "s"(rrs), "s"(so) : "memory");
     }
   };
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     for (int c = 0; c < CW; ++c) {
       const f32x4 v = acc[p][c] + bias[c];                         // per-channel constant (primal bias)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, v), cur_yrs, yvoff,
-                                             it.ypix + 4 * (p * y_px + c * 16 * y_co), 0);
+                                             it.ypix + 4 * (((p / C::TW) * a.W + p % C::TW) * y_px + c * 16 * y_co), 0);
     }
   };
   // Pixel p's residual has landed when at most N VMEM operations issued after it are outstanding.  The tail issues,
@@ -603,11 +608,11 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       return;
 #endif
       if (s < 2) {
-        bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][p & 1] + p * 256);
-        bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][p & 1] + p * 256);
-      } else {
-        bh[t % BD] = *reinterpret_cast<const bf16x8*>(ch_[p & 1] + p * 256);
-        bl[t % BD] = *reinterpret_cast<const bf16x8*>(cl_[p & 1] + p * 256);
+        bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][p & 1] + C::pl(p) * 256);
+        bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][p & 1] + C::pl(p) * 256);
+      } else {                                     // ring rows are TW pixels long, stage rows TWH: per-lane row step
+        bh[t % BD] = *reinterpret_cast<const bf16x8*>(ch_[p & 1] + p * 256 + (p / C::TW) * crow);
+        bl[t % BD] = *reinterpret_cast<const bf16x8*>(cl_[p & 1] + p * 256 + (p / C::TW) * crow);
       }
     };
 #pragma unroll
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int u = lane + 64 * k;
-        if (u < PW * 16) cp[k] = *reinterpret_cast<const u32x4*>(src + u * 16);
+        if (u < PW * 16) cp[k] = *reinterpret_cast<const u32x4*>(src + u * 16 + ((u >> 4) / C::TW) * (C::TWH - C::TW) * 256);
       }
     }
 #pragma unroll
@@ -744,7 +749,7 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned 
 template <int COT, int PXW, int MODE>
 int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   using C = BCfg<COT, PXW>;
-  const int tiles_x = cmf_ceil_div(a.W, 2 * PXW), tiles = tiles_x * cmf_ceil_div(a.H, 2);
+  const int tiles_x = cmf_ceil_div(a.W, C::TW), tiles = tiles_x * cmf_ceil_div(a.H, C::TH);
   const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
@@ -811,9 +816,9 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
     return CMF_ERANGE;
   hipStream_t s = (hipStream_t)stream;
   // the kernel has no partial-tile / partial-channel-group code: whole 2 x 14 tiles (14- and 28-wide images) or whole
-  // 2 x 8 tiles (16- / 32-wide: CIFAR; 160 of the 256 loader threads busy, so loader-bound) and whole groups of 64 (or
-  // exactly 32) output channels only
-  if ((a.W % 14 && a.W % 8) || a.H % 2 || !(a.cout % 64 == 0 || a.cout == 32)) return CMF_EINVAL;
+  // 4 x 8 tiles (16- / 32-wide: CIFAR) and whole groups of 64 (or exactly 32) output channels only
+  const bool t14 = a.W % 14 == 0 && a.H % 2 == 0, t8 = a.W % 8 == 0 && a.H % 4 == 0;
+  if (!(t14 || t8) || !(a.cout % 64 == 0 || a.cout == 32)) return CMF_EINVAL;
   if (a.bias && a.cout > 64) return CMF_EINVAL;                 // the per-channel constants are fetched once per launch
-  return a.W % 14 == 0 ? launch_cot<7>(a, s) : launch_cot<4>(a, s);
+  return t14 ? launch_cot<7>(a, s) : launch_cot<4>(a, s);
 }

@@ -100,7 +100,7 @@ def _use_bf16x3(taps, cin, W, transpose, H=None, cout=64):
 
 def _shape_ok_bf16x3(taps, cin, W, transpose, H=None, cout=64):
     """Shapes the split-precision kernel is built for: whole 2 x 14 (or 2 x 8) pixel tiles, whole 64- (or one 32-) channel groups."""
-    return (taps == 9 and cin % 8 == 0 and cin % 32 == 0 and (W % 14 == 0 or W % 8 == 0) and (H is None or H % 2 == 0)
+    return (taps == 9 and cin % 8 == 0 and cin % 32 == 0 and ((W % 14 == 0 and (H is None or H % 2 == 0)) or (W % 8 == 0 and (H is None or H % 4 == 0)))
             and (cout % 64 == 0 or cout == 32) and not transpose)
 
 

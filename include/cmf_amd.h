@@ -87,7 +87,7 @@ typedef struct {
 } cmf_conv_tangent_args;
 int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
 
-/* Split-precision variant of cmf_conv_tangent for taps == 9, cin % 32 == 0, W % 14 == 0 or W % 8 == 0, H % 2 == 0 and
+/* Split-precision variant of cmf_conv_tangent for taps == 9, cin % 32 == 0, (W % 14 == 0 and H % 2 == 0) or (W % 8 == 0 and H % 4 == 0), and
  * cout % 64 == 0 or cout == 32 (anything else: CMF_EINVAL, use cmf_conv_tangent): operands are split
  * v = hi + lo (bf16 each) and multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
  * accumulation (fp32-grade result, ~2^-16 relative per product).  `w` must come from
