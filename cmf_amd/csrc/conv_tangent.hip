@@ -326,6 +326,8 @@ int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
     const long long tiles = TAPS == 9 ? (long long)cmf_ceil_div(a.W, 2 * PXW) * cmf_ceil_div(a.H, 2)
                                       : (long long)cmf_ceil_div(a.H * a.W, 4 * PXW);
     const long long items = tiles * (a.nc / 16) * (a.cout / 64) * a.np;
+    if (items < 160) return launch<TAPS, 1, PXW>(a, s, 4);    // tiny grids (32-sample shards): the launch is one item's
+                                                                // latency -- quarter the MFMA work per item
     if (items < 1024) return launch<TAPS, 2, PXW>(a, s, 2);
   }
   const int cot = (a.cout >= 64) ? 4 : (a.cout + 15) / 16;
