@@ -3,12 +3,12 @@
 oracle on the full-size MNIST model (fixture c3_mnist_full, B = 2, d = 64) and compare log-det / likelihood / g_ij / J with
 an fp64 evaluation.  This is how the bf16x3 scheme of conv_tangent_bf16x3.hip was chosen.
 
-  python tools/emulate_precision.py [scheme ...]      schemes: f32 bf16x1 bf16x2 bf16x3 f16x1 f16x2 f16x3
+  python tests/dev/emulate_precision.py [scheme ...]      schemes: f32 bf16x1 bf16x2 bf16x3 f16x1 f16x2 f16x3
 """
 import os, sys, time
 import torch
 import torch.nn.functional as F
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_golden, golden_model
 from oracle import cmf_oracle as O
 

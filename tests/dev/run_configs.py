@@ -2,7 +2,7 @@
 """Run the other BASELINE configs at full size on the GPU: finite outputs, timing, and (small batches) oracle check."""
 import os, sys, time, json
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import cmf_amd
 from cmf_amd.recipe import fill_state_dict
 from oracle import cmf_oracle as O
