@@ -193,6 +193,16 @@ def test_product_path_has_no_cpu_fallback_and_no_oracle_import():
         if f.endswith(".py"):
             src = open(os.path.join(root, "cmf_amd", f)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+    # repo-wide: only tests/, smoke() (__graft_entry__.py) and bench.py's cpu_baseline leg touch oracle/
+    allowed = {os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")}
+    for d, _, files in os.walk(root):
+        rel = os.path.relpath(d, root)
+        if rel.split(os.sep)[0] in ("tests", "oracle", ".git", "gpurun_out", ".pytest_cache"):
+            continue
+        for f in files:
+            path = os.path.join(d, f)
+            if f.endswith(".py") and path not in allowed:
+                assert not re.search(r"^\s*(from|import)\s+oracle", open(path).read(), flags=re.M), path
 
 
 def test_dequantization_mutates_caller_tensor_like_reference():
