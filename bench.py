@@ -172,8 +172,8 @@ def main():
                 # by HBM: `hbm_view` carries the memory side.
                 line["roofline"] = {"bound": "mfma", "achieved": 3.0 * tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": 3.0 * tf / BF16_MFMA_PEAK_TFLOPS,
-                                    "kernel": "conv_tangent_bf16x3_kernel<4,7,false> (3x3, 64->64 channels, all d Jacobian "
-                                              "columns; split-precision bf16 MFMA, fp32 accumulate)",
+                                    "kernel": "conv_tangent_bf16x3_kernel<4,7,3> (<4,7,1> for the first hidden conv of each coupler; 3x3, "
+                                              "64->64 channels, all d Jacobian columns; split-precision bf16 MFMA, fp32 accumulate)",
                                     "fp32_equivalent_tflops": tf, "bf16_products_per_fp32_product": 3,
                                     "executed_bf16_tflops_with_k_padding": 4.0 * tf,
                                     "hbm_view": {"algorithmic_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS},

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcmf_amd.so")
 
-F_NONE, F_RELU, F_TANH, F_RAW, F_SELF_RELU = 0, 1, 2, 3, 4
+F_NONE, F_RELU, F_TANH, F_RAW, F_SELF_RELU, F_RELU_BITS = 0, 1, 2, 3, 4, 5
 O_NONE, O_TANH, O_STANH = 0, 1, 2
 
 _fp = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
@@ -25,7 +25,8 @@ class ConvTangentArgs(C.Structure):
                 ("r", _fp), ("r_np", _ll), ("r_co", _ll), ("r_px", _ll),
                 ("np", _i), ("cin", _i), ("cout", _i), ("H", _i), ("W", _i), ("nc", _i), ("taps", _i),
                 ("bias", _fp), ("f_group", _i), ("x_sl", _ll), ("y_sl", _ll), ("r_sl", _ll),
-                ("fo", _fp), ("fo_np", _ll), ("fo_co", _ll), ("fo_px", _ll), ("fomode", _i)]
+                ("fo", _fp), ("fo_np", _ll), ("fo_co", _ll), ("fo_px", _ll), ("fomode", _i),
+                ("mask_out", _fp), ("mask_np", _ll)]
 
 
 class ConvPrimalArgs(C.Structure):

@@ -133,7 +133,9 @@ class AffineCouplingBijection(Bijection):
 
     def decode_(self, z, T=None, lj=None):
         view = self.view(z.device)
-        y, g, acts = E.net_primal(self.net, z, view, need_acts=T is not None)
+        # the split-precision tangent pass reads relu' from bit masks written by the primal pass (engine.BitMask)
+        want = False if T is None else ("bits" if E.TANGENT_PRECISION == "bf16x3" else True)
+        y, g, acts = E.net_primal(self.net, z, view, need_acts=want)
         if T is not None:
             YT = E.net_tangent(self.net, T, view, acts)
             E.acl_tangent(T, YT, z, y, g, self.maps(z.device))      # uses z BEFORE the primal update

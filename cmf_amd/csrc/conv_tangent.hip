@@ -285,6 +285,20 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
           f32x4 v = acc[p][c] * mo + bias[c];
           if (has_res) v += *reinterpret_cast<const f32x4*>(rp + (c * 16) * r_co);
           *reinterpret_cast<f32x4*>(yp + (c * 16) * y_co) = v;
+          if (a.mask_out) {                                // wave-uniform; launcher: cout % 16 == 0, so every lane is here
+            // sign bits for the next conv's relu' (CMF_F_RELU_BITS): ballot r covers column kq*4 + r of 16 channels per
+            // lane group; lane (kq, cl < 4) writes the 16 channel bits of column kq*4 + cl
+            const unsigned long long b0 = __ballot(v[0] > 0.f), b1 = __ballot(v[1] > 0.f), b2 = __ballot(v[2] > 0.f),
+                                     b3 = __ballot(v[3] > 0.f);
+            const int ccl = cl & 3;
+            const unsigned long long bb = ccl == 0 ? b0 : ccl == 1 ? b1 : ccl == 2 ? b2 : b3;
+            if (cl < 4) {
+              const long long sample = (long long)np * a.nc + slice * 16 + kq * 4 + cl;
+              unsigned char* mp = reinterpret_cast<unsigned char*>(a.mask_out) + sample * a.mask_np +
+                                  (long long)gpix * (a.cout / 8) + (cog * 64 + cosub + c * 16) / 8;
+              *reinterpret_cast<unsigned short*>(mp) = (unsigned short)(bb >> (kq * 16));
+            }
+          }
         }
       }
     }
@@ -356,6 +370,7 @@ extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
   if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;            // 16-byte stores
   if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;    // 16-byte residual loads
   if (a.fo && (a.fomode < CMF_F_RELU || a.fomode > CMF_F_RAW)) return CMF_EINVAL;
+  if (a.mask_out && (a.cout % 16 || a.mask_np < (long long)a.H * a.W * (a.cout / 8))) return CMF_EINVAL;
   const long long HW = (long long)a.H * a.W;
   // per-sample offsets are held in 32-bit registers
   if (!fits_int((a.cin + 8) * a.x_ci + HW * a.x_px + a.nc) || !fits_int((a.cin + 8) * a.f_ci + HW * a.f_px) ||

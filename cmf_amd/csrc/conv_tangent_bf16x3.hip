@@ -106,7 +106,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // MODE: 0 = general factor formula, 1 = relu factor (2 instead of 6 VALU per channel in the loader), 2 = SELF (the
   // input's own relu, no factor stream).  Compile-time: every loader VALU instruction delays the MFMA wave it shares
   // a SIMD with.
-  constexpr bool SELF = MODE == 2, RELU = MODE == 1;
+  constexpr bool SELF = MODE == 2, RELU = MODE == 1, BITS = MODE == 3;   // 3 = relu' from a bit mask (CMF_F_RELU_BITS)
+  constexpr int NF = SELF ? 0 : BITS ? 1 : 8;                    // factor loads per loader thread and chunk
   using C = BCfg<COT, PXW>;
   constexpr int CW = COT / 2, PW = C::PW;
   static_assert(COT % 2 == 0, "the co-split wave layout needs an even number of output-channel tiles");
@@ -195,13 +196,14 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       decode(item, tile, slice, cog, np);
       const int y0 = C::TH * (tile / tiles_x), x0 = C::TW * (tile % tiles_x);
       xrs = make_rsrc(a.x + (long long)np * a.x_np + (long long)slice * (a.x_sl ? a.x_sl : 16));
-      frs = make_rsrc(a.f ? a.f + (long long)(np / fgrp) * a.f_np + (np % fgrp) : a.x);
+      frs = BITS ? make_rsrc(reinterpret_cast<const unsigned char*>(a.f) + (long long)np * a.f_np)        // f_np in bytes
+                 : make_rsrc(a.f ? a.f + (long long)(np / fgrp) * a.f_np + (np % fgrp) : a.x);
       const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
       const bool ok = lt < C::NX_ITEMS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       const int gpix = gy * a.W + gx;
       okf = ok ? 1.f : 0.f;
       xo = ok ? 4 * (gpix * x_px + q * 4) : 0;
-      fo = ok ? 4 * (gpix * f_px) : 0;
+      fo = ok ? (BITS ? gpix * (a.cin / 8) : 4 * (gpix * f_px)) : 0;
     };
     // per-thread byte offsets of its W items inside a chunk slab (loop-invariant).  COT == 4 consumes the slab whole
     // (a linear copy): ONE register, the item stride goes into soffset.
@@ -274,7 +276,9 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
             : "v"(xo), "s"(xrs), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(s6), "s"(s7)
             : "memory");
       }
-      if (has_f) {
+      if constexpr (BITS) {                                        // one byte: the chunk's 8 relu' bits of this pixel
+        asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %1, %2, %3 offen" : "=&v"(r.f[0]) : "v"(fo), "s"(frs), "s"(ch) : "memory");
+      } else if (has_f) {
         const int s0 = 4 * (ch * 8 + 0) * f_ci, s1 = 4 * (ch * 8 + 1) * f_ci, s2 = 4 * (ch * 8 + 2) * f_ci,
                   s3 = 4 * (ch * 8 + 3) * f_ci, s4 = 4 * (ch * 8 + 4) * f_ci, s5 = 4 * (ch * 8 + 5) * f_ci,
                   s6 = 4 * (ch * 8 + 6) * f_ci, s7 = 4 * (ch * 8 + 7) * f_ci;
@@ -303,7 +307,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     // hand-counted waits; the "+v" operands make every consumer of the set depend on the wait statement
     constexpr int NW = C::NWIT;
     auto wait_x = [&](Regs& r) {                                   // X,f of `r` landed; W, X,f, W, X,f may still fly
-      if constexpr (has_f)
+      if constexpr (BITS)
+        asm volatile("s_waitcnt vmcnt(%9)"
+                     : "+v"(r.x[0]), "+v"(r.x[1]), "+v"(r.x[2]), "+v"(r.x[3]), "+v"(r.x[4]), "+v"(r.x[5]), "+v"(r.x[6]),
+                       "+v"(r.x[7]), "+v"(r.f[0])
+                     : "n"(2 * NW + 2 * (8 + NF)));
+      else if constexpr (has_f)
         asm volatile("s_waitcnt vmcnt(%16)"
                      : "+v"(r.x[0]), "+v"(r.x[1]), "+v"(r.x[2]), "+v"(r.x[3]), "+v"(r.x[4]), "+v"(r.x[5]), "+v"(r.x[6]),
                        "+v"(r.x[7]), "+v"(r.f[0]), "+v"(r.f[1]), "+v"(r.f[2]), "+v"(r.f[3]), "+v"(r.f[4]), "+v"(r.f[5]),
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     };
     auto wait_w = [&]() {                                          // the slab landed; the newest X,f may still fly
       static_assert(C::NWIT == 6 || C::NWIT == 3, "operand list below");
-      constexpr int N = has_f ? 16 : 8;
+      constexpr int N = 8 + NF;
       if constexpr (C::NWIT == 6)
         asm volatile("s_waitcnt vmcnt(%6)"
                      : "+v"(wreg[0]), "+v"(wreg[1]), "+v"(wreg[2]), "+v"(wreg[3]), "+v"(wreg[4]), "+v"(wreg[5])
@@ -348,7 +357,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float f = r.f[j];
-          const float m = SELF ? r.okf : RELU ? (f > 0.f ? r.okf : 0.f)
+          const float m = SELF ? r.okf : BITS ? (((__builtin_bit_cast(unsigned, r.f[0]) >> j) & 1u) ? r.okf : 0.f)
+                               : RELU ? (f > 0.f ? r.okf : 0.f)
                                               : r.okf * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[j][c] = (SELF ? fmaxf(r.x[j][c], 0.f) : r.x[j][c]) * m;
@@ -778,6 +788,7 @@ int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
   // co tiles per workgroup: 64 / 32 channels; factor code specialised for self-relu / relu / anything else
   if (a.fmode == CMF_F_SELF_RELU) return (a.cout > 32) ? launch<4, PXW, 2>(a, s) : launch<2, PXW, 2>(a, s);
   if (a.fmode == CMF_F_RELU) return (a.cout > 32) ? launch<4, PXW, 1>(a, s) : launch<2, PXW, 1>(a, s);
+  if (a.fmode == CMF_F_RELU_BITS) return (a.cout > 32) ? launch<4, PXW, 3>(a, s) : launch<2, PXW, 3>(a, s);
   return (a.cout > 32) ? launch<4, PXW, 0>(a, s) : launch<2, PXW, 0>(a, s);
 }
 
@@ -802,10 +813,11 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   const cmf_conv_tangent_args& a = *ap;
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
   if (a.taps != 9 || a.cin % 32 || a.nc <= 0 || a.nc % 16) return CMF_EINVAL;   // K packing works on groups of 4 octets
-  if (a.fmode <= CMF_F_NONE || a.fmode > CMF_F_SELF_RELU) return CMF_EINVAL;   // NONE: use cmf_conv_tangent (the loader's
+  if (a.fmode <= CMF_F_NONE || a.fmode > CMF_F_RELU_BITS) return CMF_EINVAL;   // NONE: use cmf_conv_tangent (the loader's
                                                                               // load schedule always carries a factor stream)
   if (a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
-  if (a.fo) return CMF_EINVAL;                                  // output-side factors: cmf_conv_tangent only
+  if (a.fo || a.mask_out) return CMF_EINVAL;                    // output-side factors / sign-bit output: cmf_conv_tangent only
+  if (a.fmode == CMF_F_RELU_BITS && a.f_np < (long long)a.H * a.W * (a.cin / 8)) return CMF_EINVAL;
   if ((a.x_np | a.x_ci | a.x_px | a.x_sl | a.y_sl | a.r_sl) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
   if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;            // 16-byte stores
   if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;    // 16-byte residual loads

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import (F_NONE, F_RELU, F_TANH, F_RAW, F_SELF_RELU, O_NONE, O_TANH, O_STANH, ConvPrimalArgs,
+from ._lib import (F_NONE, F_RELU, F_TANH, F_RAW, F_SELF_RELU, F_RELU_BITS, O_NONE, O_TANH, O_STANH, ConvPrimalArgs,
                    ConvTangentArgs)
 
 
@@ -207,7 +207,8 @@ def conv_primal(x_ptr_t, x_off, x_b, x_c, x_px, weight, taps, bias, y, y_b, y_c,
 
 def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_px, np_, cin, cout, H, W, nc,
                  fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, res_t=None, transpose=False, bias=None, f_group=1,
-                 x_sl=16, y_sl=16, precision=None, y_off=0, res_off=0, fo=None, fo_np=0, fo_co=0, fo_px=0, fomode=F_NONE):
+                 x_sl=16, y_sl=16, precision=None, y_off=0, res_off=0, fo=None, fo_np=0, fo_co=0, fo_px=0, fomode=F_NONE,
+                 mask_out=None, mask_np=0):
     """``fo`` = OUTPUT-side factor (reverse sweep, fp32 kernel only); ``y_off`` / ``res_off`` = element offsets into
     ``y_t`` / ``res_t`` (in-place accumulation into a strided view of a larger tensor)."""
     lib = _lib.load()
@@ -221,6 +222,9 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     a.r = None if res_t is None else C.c_void_p(res_t.data_ptr() + 4 * int(res_off))
     a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
     a.fo = _p(fo); a.fo_np, a.fo_co, a.fo_px, a.fomode = int(fo_np), int(fo_co), int(fo_px), int(fomode)
+    a.mask_out = _p(mask_out); a.mask_np = int(mask_np)
+    assert not (fmode == F_RELU_BITS and not split), "bit-mask factors are read by the split-precision kernel only"
+    assert not (mask_out is not None and split), "sign bits are written by the fp32 kernel only"
     a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), int(taps)
     a.bias = _p(bias); a.f_group = int(f_group)
     a.x_sl, a.y_sl, a.r_sl = int(x_sl), int(y_sl), int(y_sl)
@@ -473,21 +477,37 @@ class GroupedActs(list):
     f_group = 16
 
 
+class BitMask:
+    """relu' of a hidden activation as one bit per (sample, pixel, channel): ``data`` (B, HW, C/8) uint8, the
+    CMF_F_RELU_BITS layout (include/cmf_amd.h).  Written by the primal conv that produces the activation."""
+
+    def __init__(self, B, HW, C, device):
+        self.data = torch.empty(B, HW, C // 8, dtype=torch.uint8, device=device)
+        self.np_bytes = HW * (C // 8)
+
+
 def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts):
-    """Hidden 3x3 convs of the primal ResNet through the split-precision tangent kernel: the 16 column slots carry 16
-    samples (relu applied elementwise on load, bias as accumulator init), ~4x the rate of the fp32 primal kernel."""
+    """Hidden 3x3 convs of the primal ResNet through the TANGENT conv kernels: the 16 column slots carry 16 samples (relu
+    applied elementwise on load, bias as per-channel constant); ``PRIMAL_PRECISION`` picks the kernel.
+    need_acts: False (encode pass, sampling), True (float activations in the standard layout: fp32 tangent path, reverse
+    sweep) or "bits" (the split-precision tangent pass follows: the fp32 kernel writes relu' bit masks next to each
+    activation, 1/32 of the bytes, and nothing is regrouped but the last activation, which the 1x1 conv reads as floats)."""
     HW, G, dev = H * W, B // 16, a0.device
     pn = (hid * HW * 16, HW * 16, 16)                       # (np, chan, px) strides of a grouped tensor
     new = lambda: torch.empty(G * hid * HW * 16, dtype=torch.float32, device=dev)
+    bits = need_acts == "bits" and PRIMAL_PRECISION == "f32" and hid % 16 == 0
     a = primal_regroup(a0, True)
-    acts = [a]
+    acts, masks = [a], []
     for blk in blocks:
         c1, a2 = new(), new()
+        m1, m2 = (BitMask(B, HW, hid, dev), BitMask(B, HW, hid, dev)) if bits else (None, None)
+        mo = lambda m: dict(mask_out=m.data, mask_np=m.np_bytes) if m is not None else {}
         conv_tangent(a, 0, *pn, blk.conv1.weight, 9, c1, *pn, G, hid, hid, H, W, 16, fmode=F_SELF_RELU, bias=blk.conv1.bias,
-                     precision=PRIMAL_PRECISION)
+                     precision=PRIMAL_PRECISION, **mo(m1))
         conv_tangent(c1, 0, *pn, blk.conv2.weight, 9, a2, *pn, G, hid, hid, H, W, 16, fmode=F_SELF_RELU, bias=blk.conv2.bias,
-                     res_t=a, precision=PRIMAL_PRECISION)
+                     res_t=a, precision=PRIMAL_PRECISION, **mo(m2))
         acts += [c1, a2]
+        masks += [m1, m2]
         a = a2
     # 1x1 + ScaledTanh on the grouped tensor: a 1x1 conv does not care that "pixels" are (pixel, sample) pairs
     yg = torch.empty(G * cout * HW * 16, dtype=torch.float32, device=dev)
@@ -499,10 +519,12 @@ def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts
     g = primal_regroup(gg.view(G, -1), False).view(B, cout, H, W)
     if not need_acts:
         return y, g, None
+    std_of = lambda t: primal_regroup(t.view(G, -1), False).view(B, hid, H, W)
+    if bits:
+        return y, g, [a0] + masks[:-1] + [std_of(acts[-1])]
     # The tangent pass reads relu' per (channel, pixel) of ONE sample: from the grouped layout every such read is its
-    # own 64-byte line (measured: tangent convs 3.1 -> 4.5 ms); regrouping the 17 saved activations costs ~4 ms / elbo.
-    std = [a0] + [primal_regroup(t.view(G, -1), False).view(B, hid, H, W) for t in acts[1:]]
-    return y, g, std
+    # own 64-byte line (measured: tangent convs 3.1 -> 4.5 ms); regrouping the 17 saved activations costs ~6 ms / elbo.
+    return y, g, [a0] + [std_of(t) for t in acts[1:]]
 
 
 def net_tangent(net, T, view, acts, transpose_packs=False):
@@ -526,13 +548,14 @@ def net_tangent(net, T, view, acts, transpose_packs=False):
                      f_ci=HW, f_px=1, y_sl=hsl)
         fg = getattr(acts, "f_group", 1)                     # primal activations: (B,C,H,W) or (B/16,C,H,W,16)
         fs = dict(f_np=hid * HW * fg, f_ci=HW * fg, f_px=fg, f_group=fg)
+        # relu' source of a hidden conv: float activations, or the bit mask the primal pass wrote (BitMask)
+        fk = lambda t: dict(fmode=F_RELU_BITS, f=t.data, f_np=t.np_bytes) if isinstance(t, BitMask) else dict(fmode=F_RELU, f=t, **fs)
         u, h2 = new(hid), new(hid)
         for k, blk in enumerate(blocks):
             a_in, c1 = acts[2 * k], acts[2 * k + 1]
-            conv_tangent(h.data, 0, *hd, blk.conv1.weight, 9, u.data, *hd, B, hid, hid, H, W, nc, fmode=F_RELU,
-                         f=a_in, x_sl=hsl, y_sl=hsl, **fs)
-            conv_tangent(u.data, 0, *hd, blk.conv2.weight, 9, h2.data, *hd, B, hid, hid, H, W, nc, fmode=F_RELU,
-                         f=c1, res_t=h.data, x_sl=hsl, y_sl=hsl, **fs)
+            conv_tangent(h.data, 0, *hd, blk.conv1.weight, 9, u.data, *hd, B, hid, hid, H, W, nc, x_sl=hsl, y_sl=hsl, **fk(a_in))
+            conv_tangent(u.data, 0, *hd, blk.conv2.weight, 9, h2.data, *hd, B, hid, hid, H, W, nc, res_t=h.data, x_sl=hsl,
+                         y_sl=hsl, **fk(c1))
             h, h2 = h2, h
         yt = new(cout)
         conv_tangent(h.data, 0, *hd, convf.weight, 1, yt.data, *pn(cout), B, hid, cout, H, W, nc, fmode=F_RELU,

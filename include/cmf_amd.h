@@ -36,6 +36,10 @@ extern "C" {
 #define CMF_F_TANH 2      /* 1 - f*f           tanh'  with f = tanh output: :42-44       */
 #define CMF_F_RAW  3      /* f itself          checkerboard mask: acl.py:54              */
 #define CMF_F_SELF_RELU 4 /* relu of the input itself, elementwise (primal data carried in the column slots) */
+#define CMF_F_RELU_BITS 5 /* relu' from a BIT MASK (cmf_conv_tangent_bf16x3 only): f points to bytes, one per (sample, pixel,
+                             8-channel octet): bit j of f[np*f_np + px*(cin/8) + ci/8] = [activation(ci = 8*(ci/8)+j) > 0];
+                             f_np in BYTES.  Written by cmf_conv_tangent's mask_out (below): 1/32 of the bytes of the
+                             activation tensor, one byte load per loader thread and chunk instead of eight dwords */
 
 /* primal epilogues */
 #define CMF_O_NONE  0
@@ -84,6 +88,10 @@ typedef struct {
                                                    by fomode like F from f (NONE / RELU / TANH / RAW).  This is what the
                                                    reverse (cotangent) sweep needs: the adjoint of "mask, then conv" is
                                                    "transposed conv, then mask" (weights from cmf_pack_weight(transpose=1)) */
+  void* mask_out; long long mask_np;            /* cmf_conv_tangent only, cout % 16 == 0: also write the sign bits of the
+                                                   stored values, [y > 0], in the CMF_F_RELU_BITS layout of the NEXT conv:
+                                                   byte (sample*mask_np + px*(cout/8) + co/8), sample = np*nc + column
+                                                   (primal pass: 16 samples in the column slots); NULL = off            */
 } cmf_conv_tangent_args;
 int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
 

@@ -62,7 +62,7 @@ def test_struct_layouts_match_header():
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
         for decl in body.split(";"):
-            ids = re.sub(r"\b(const|float|int|long)\b", "", decl).replace("*", "")
+            ids = re.sub(r"\b(const|float|int|long|void|unsigned|char)\b", "", decl).replace("*", "")
             names += [t.strip() for t in ids.split(",") if t.strip()]
         return names
 

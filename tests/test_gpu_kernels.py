@@ -138,3 +138,37 @@ def test_conv_tangent_primal_in_column_slots(H, W, precision, monkeypatch):
     E.conv_tangent(v.cuda(), 0, C * HW * nc, HW * nc, nc, wd, 9, yv, C * HW * nc, HW * nc, nc, B, C, C, H, W, nc,
                    fmode=E.F_RELU, f=xg, f_np=C * HW * 16, f_ci=HW * 16, f_px=16, f_group=16)
     assert rel(yv, wantv) < 2e-5
+
+
+@pytest.mark.parametrize("H,W", [(14, 14), (16, 16)])
+def test_relu_bit_masks_producer_and_consumer(H, W, monkeypatch):
+    """The fp32 kernel's ``mask_out`` (sign bits of what it stores, one bit per sample / pixel / channel) and the split
+    kernel's CMF_F_RELU_BITS factor mode: same tangent conv result as the float-activation RELU mode, bit for bit."""
+    from cmf_amd import engine as E
+    monkeypatch.setattr(E, "TANGENT_PRECISION", "bf16x3")
+    gen = torch.Generator().manual_seed(H)
+    B, C, nc, HW = 32, 64, 32, H * W
+    G = B // 16
+    # producer: a primal conv with 16 samples in the column slots writes activations (grouped) and their sign bits
+    x = torch.randn(B, C, H, W, generator=gen)
+    w1 = torch.nn.Parameter((torch.randn(C, C, 3, 3, generator=gen) / 24).cuda())
+    b1 = torch.randn(C, generator=gen).cuda()
+    xg = E.primal_regroup(x.cuda(), True)
+    act_g = torch.empty(G * C * HW * 16, device="cuda")
+    m = E.BitMask(B, HW, C, "cuda")
+    m.data.fill_(0xAA)
+    pn = (C * HW * 16, HW * 16, 16)
+    E.conv_tangent(xg, 0, *pn, w1, 9, act_g, *pn, G, C, C, H, W, 16, fmode=E.F_SELF_RELU, bias=b1, precision="f32",
+                   mask_out=m.data, mask_np=m.np_bytes)
+    act = E.primal_regroup(act_g.view(G, -1), False).view(B, C, H, W)
+    want_bits = (act > 0).permute(0, 2, 3, 1).reshape(B, HW, C // 8, 8)                     # bit j of byte o = channel 8*o + j
+    want = (want_bits.to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(m.data, want)
+    # consumer: the same tangent conv with relu' from the floats and from the bits
+    st, sl = (C * HW * nc, 16, C * nc), C * 16
+    T = torch.randn(B * C * HW * nc, generator=gen).cuda()
+    w2 = torch.nn.Parameter((torch.randn(C, C, 3, 3, generator=gen) / 24).cuda())
+    y1, y2 = torch.empty_like(T), torch.empty_like(T)
+    E.conv_tangent(T, 0, *st, w2, 9, y1, *st, B, C, C, H, W, nc, fmode=E.F_RELU, f=act, f_np=C * HW, f_ci=HW, f_px=1, x_sl=sl, y_sl=sl)
+    E.conv_tangent(T, 0, *st, w2, 9, y2, *st, B, C, C, H, W, nc, fmode=E.F_RELU_BITS, f=m.data, f_np=m.np_bytes, x_sl=sl, y_sl=sl)
+    assert torch.equal(y1, y2)
