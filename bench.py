@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--primal-precision", choices=["f32", "bf16x3"], default="f32",
                     help="arithmetic of the PRIMAL hidden convs (relu masks come from these activations): f32 = exact fp32 "
                          "products (default, parity-grade), bf16x3 = split precision, ~9 %% faster (DESIGN.md 4.2)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 "
+                                                       "on a one-GPU box together with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (never a measurement)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -100,11 +103,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", 0 if args.share_gpu else local)
     torch.cuda.set_device(device)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from cmf_amd import engine as E
     from cmf_amd.distributed import allreduce_mean_elbo
@@ -152,7 +158,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f32 (3x3 tangent convs as bf16x3 split MFMA, fp32 accumulate)",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, not a measurement)" if args.share_gpu else ""),
             "config": {"workload": "C3: MNIST-shaped (1,28,28) uint8-range + U[0,1) noise, non-square flow d=64, "
                                    "cholesky J^T J log-det + g_ij off-diagonal L1 + reconstruction, eval/no_grad",
                        "per_gpu_batch": B, "global_batch": B * world, "D": 784, "latent_dimension": 64,
@@ -167,7 +173,7 @@ def main():
             if E.TANGENT_PRECISION == "bf16x3":
                 # Split precision: every fp32-grade product is THREE bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the
                 # matrix work this algorithm needs is 3x the algorithmic fp32 flops; `achieved` counts exactly that
-                # (the 25 % zero-weight K padding the kernel also executes is NOT counted) against the dense bf16 peak.
+                # (nothing else: the K packing has no zero-weight padding) against the dense bf16 peak.
                 # Measured with in-kernel stamps the kernel is bound by SIMD issue (MFMA + the loader waves' VALU), not
                 # by HBM: `hbm_view` carries the memory side.
                 line["roofline"] = {"bound": "mfma", "achieved": 3.0 * tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -175,7 +181,6 @@ def main():
                                     "kernel": "conv_tangent_bf16x3_kernel<4,7,3> (<4,7,1> for the first hidden conv of each coupler; 3x3, "
                                               "64->64 channels, all d Jacobian columns; split-precision bf16 MFMA, fp32 accumulate)",
                                     "fp32_equivalent_tflops": tf, "bf16_products_per_fp32_product": 3,
-                                    "executed_bf16_tflops_with_k_padding": 4.0 * tf,
                                     "hbm_view": {"algorithmic_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS},
                                     **common}
             else:

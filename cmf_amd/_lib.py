@@ -57,6 +57,7 @@ SIGNATURES = {
     "cmf_seed_tangent": (_i, [_fp, _ll, _ll, _fp, _i, _i, _fp, _i, _i, _i, _fp]),
     "cmf_gram_cholesky": (_i, [_fp, _ll, _ll, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "cmf_cholesky_retry": (_i, [_fp, _i, _i, _i, _f, _fp, _fp, _fp, _fp, _fp]),
+    "cmf_gram_backward": (_i, [_fp, _ll, _ll, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _ll, _ll, _fp]),
     "cmf_prehead": (_i, [_fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _fp]),
     "cmf_prehead_inverse": (_i, [_fp, _fp, _f, _f, _i, _ll, _fp]),
     "cmf_gaussian_logprob": (_i, [_fp, _ll, _i, _i, _fp, _fp]),

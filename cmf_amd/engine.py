@@ -332,6 +332,19 @@ def gram_cholesky(T, d, max_attempts=6, eps0=1e-6):
     return r
 
 
+def gram_backward(T, jtj, g_logdet=None, g_l1off=None, g_l1diag=None):
+    """Cotangent of the Jacobian stack T for a loss with d/d logdet = g_logdet, d/d l1_off = g_l1off, d/d l1_diag =
+    g_l1diag (each (B,) or None): what autograd yields through non_square.py:307-308, :280-294, :87-100."""
+    B, d = jtj.shape[0], jtj.shape[1]
+    assert B == T.B and d <= T.nc
+    dT = T.like(T.N)
+    gs = [None if g is None else g.to(torch.float32).contiguous() for g in (g_logdet, g_l1off, g_l1diag)]
+    _lib.check(_lib.load().cmf_gram_backward(_p(T.data), T.t_b, T.t_r, T.N, T.nc, d, B, _p(jtj),
+                                             *[None if g is None else _p(g) for g in gs], _p(dT.data), dT.t_b, dT.t_r,
+                                             _stream()), "cmf_gram_backward")
+    return dT
+
+
 def hutch_cg(jtj, eps, max_iter, tol, min_iter=None):
     """Hutchinson surrogate on explicit J^T J: returns (value (B,), u, w (B,d,S), iterations (B,))."""
     B, d, S = eps.shape

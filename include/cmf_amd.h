@@ -182,6 +182,14 @@ int cmf_gram_cholesky(const float* t, long long t_b, long long t_r, int n_rows, 
                       void* stream);
 int cmf_cholesky_retry(float* jtj, int d, int B, int attempt, float eps0, float* logdet, float* l1_diag,
                        int* info, int* fail, void* stream);
+/* Reverse of the head above for training (autograd through non_square.py:307-308, :280-294, :87-100):
+ *   dt(b, r, :) = 2 * t(b, r, :) * (g_logdet[b] * jtj_b^-1 + g_l1off[b] * sign(jtj_b)[i != j]
+ *                                   + g_l1diag[b] * sign(jtj_b)[i == j])
+ * jtj is the matrix cmf_gram_cholesky / cmf_cholesky_retry left behind; g_* are [B] or NULL (= 0);
+ * dt has nc columns per row like t (columns >= d are written as 0) and may not alias t.            */
+int cmf_gram_backward(const float* t, long long t_b, long long t_r, int n_rows, int nc, int d, int B,
+                      const float* jtj, const float* g_logdet, const float* g_l1off, const float* g_l1diag,
+                      float* dt, long long dt_b, long long dt_r, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small per-sample reductions / elementwise maps.                                                 */

@@ -107,6 +107,41 @@ def test_gram_cholesky(N, d, layout):
     assert gr.fail.tolist()[0] == 0
 
 
+@pytest.mark.parametrize("N,d,layout", [(784, 64, "panel"), (300, 128, "panel"), (100, 20, "fmajor"), (48, 2, "panel"), (50, 33, "fmajor")])
+def test_gram_backward_matches_autograd(N, d, layout):
+    """dJ of  sum_b a_b logdet(J^T J) + o_b sum_{i!=j} |G_ij| + c_b sum_i |G_ii|  against torch.autograd in float64."""
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(3 * N + d)
+    B, nc = 6, E.ceil16(d)
+    J = torch.zeros(B, N, nc)
+    J[:, :, :d] = torch.randn(B, N, d, generator=gen)
+    ga, go, gd = (torch.randn(B, generator=gen) for _ in range(3))
+    data = J if layout == "panel" else J.permute(1, 0, 2)
+    T = E.Tangent(B, N, nc, layout, "cuda", data=data.contiguous().reshape(-1).cuda())
+    gr = E.gram_cholesky(T, d)
+    assert gr.fail.tolist()[0] == 0
+    Jd = J[:, :, :d].double().requires_grad_(True)
+    G = torch.einsum("bni,bnj->bij", Jd, Jd)
+    diag = torch.diagonal(G, dim1=1, dim2=2).abs().sum(1)
+    loss = (ga.double() * torch.linalg.slogdet(G)[1] + go.double() * (G.abs().sum((1, 2)) - diag) + gd.double() * diag).sum()
+    loss.backward()
+    for sel in [(1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1)]:
+        if sel == (1, 1, 1):
+            want = Jd.grad
+        else:
+            Jd.grad = None
+            G = torch.einsum("bni,bnj->bij", Jd, Jd)
+            diag = torch.diagonal(G, dim1=1, dim2=2).abs().sum(1)
+            (sel[0] * ga.double() * torch.linalg.slogdet(G)[1] + sel[1] * go.double() * (G.abs().sum((1, 2)) - diag)
+             + sel[2] * gd.double() * diag).sum().backward()
+            want = Jd.grad
+        args = [g.cuda() if on else None for g, on in zip((ga, go, gd), sel)]
+        dT = E.gram_backward(T, gr.jtj, *args)
+        got = dT.to_dense(nc)
+        assert rel(got[:, :, :d], want) < 1e-4
+        assert float(got[:, :, d:].abs().max()) == 0.0 if d < nc else True
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("H,W", [(14, 14), (28, 28), (5, 14)])
 def test_conv_tangent_primal_in_column_slots(H, W, precision, monkeypatch):
