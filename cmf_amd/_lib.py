@@ -15,6 +15,7 @@ _fp = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
 _ll = C.c_longlong
 _i = C.c_int
 _f = C.c_float
+_d = C.c_double
 
 
 class ConvTangentArgs(C.Structure):
@@ -57,6 +58,8 @@ SIGNATURES = {
     "cmf_seed_tangent": (_i, [_fp, _ll, _ll, _fp, _i, _i, _fp, _i, _i, _i, _fp]),
     "cmf_gram_cholesky": (_i, [_fp, _ll, _ll, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "cmf_cholesky_retry": (_i, [_fp, _i, _i, _i, _f, _fp, _fp, _fp, _fp, _fp]),
+    "cmf_grad_sqnorm": (_i, [_fp, _ll, _fp, _fp, _fp]),
+    "cmf_optimizer_step": (_i, [_i, _fp, _fp, _fp, _fp, _ll, _d, _d, _d, _d, _d, _i, _fp, _f, _fp]),
     "cmf_gram_backward": (_i, [_fp, _ll, _ll, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _ll, _ll, _fp]),
     "cmf_prehead": (_i, [_fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _fp]),
     "cmf_prehead_inverse": (_i, [_fp, _fp, _f, _f, _i, _ll, _fp]),

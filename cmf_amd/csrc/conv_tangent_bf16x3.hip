@@ -353,6 +353,21 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         // takes any two registers, so the (channel 2jj, 2jj+1) packing is free.  ~3 VALU per element.
         // SCALAR f32 multiplies / subtractions on purpose (and -fno-slp-vectorize for this file): beside a saturating
         // MFMA wave a v_pk_mul/fma_f32 costs ~20 cycles more than the two scalar ops it replaces.
+#ifdef CMF_DBG_RAWCOMMIT
+        // timing only: no mask, no split -- truncated bf16 pairs (one v_perm per pair) into both planes
+        asm volatile("" ::"v"(r.f[0]));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          u32x4 h;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            h[jj] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r.x[2 * jj + 1][c]),
+                                          __builtin_bit_cast(unsigned, r.x[2 * jj][c]), 0x07060302u);
+          const int off = ((pix * 16 + xslot(q * 4 + c, pix)) << 4);
+          *reinterpret_cast<u32x4*>(Xh + off) = h;
+          *reinterpret_cast<u32x4*>(Xl + off) = h;
+        }
+#else
         float v[8][4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -380,6 +395,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
           *reinterpret_cast<u32x4*>(Xl + off) = l;
           if (c == 1) __builtin_amdgcn_sched_barrier(0);           // bounds the live temporaries
         }
+#endif
       }
       wait_w();
 #pragma unroll

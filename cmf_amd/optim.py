@@ -1,0 +1,143 @@
+"""Flat-buffer optimiser for the density's parameters ("fused Adam step").
+
+The reference creates ``torch.optim.{SGD, Adam, Adamax}(params, lr=..., weight_decay=...)`` per objective
+(``experiment.py:515-534``) and steps it after an optional ``clip_grad_norm_`` (``trainer.py:213-221``).  The MNIST
+model has 486 parameter tensors of 24 MB in all: a per-tensor loop is 486+ launches per step.  ``FlatOptimizer``
+
+* moves every parameter into ONE flat fp32 buffer (each ``Parameter.data`` becomes a view of it) and gives every
+  parameter a ``.grad`` that is a view of ONE flat gradient buffer -- which is also exactly the bucket the data-parallel
+  all-reduce wants (``allreduce_flat``: one RCCL call over xGMI, no packing copies);
+* steps with ``cmf_optimizer_step`` (one elementwise launch, 28 B of HBM traffic per parameter for Adam / Adamax) after
+  ``cmf_grad_sqnorm`` when ``max_grad_norm`` is set; the clip coefficient is read on the device (no host sync).
+
+Same arithmetic as torch's optimisers (no amsgrad / momentum); ``state_dict`` / ``load_state_dict`` follow the
+``{"state": {idx: {"step", "exp_avg", "exp_avg_sq" | "exp_inf"}}, "param_groups": [...]}`` schema so that the
+``opt_state_dict`` entries of a reference checkpoint (``trainer.py:362-400``) load.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+KINDS = {"sgd": 0, "adam": 1, "adamax": 2}
+_SECOND = {"adam": "exp_avg_sq", "adamax": "exp_inf"}
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class FlatOptimizer:
+    def __init__(self, params, opt="adam", lr=1e-3, weight_decay=0., betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
+        if opt not in KINDS:
+            raise AssertionError(f"Invalid optimiser type {opt}")       # experiment.py:522
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("cmf_amd.optim.FlatOptimizer steps through the HIP kernel: parameters must be on the GPU")
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("all parameters must be float32 on one device")
+        self.opt, self.lr, self.weight_decay, self.betas, self.eps = opt, float(lr), float(weight_decay), betas, float(eps)
+        self.max_grad_norm = max_grad_norm
+        self.t = 0
+        # 16-byte aligned slots: every tensor starts on a multiple of 4 floats, the gaps stay zero forever (g = 0 there)
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.n = n
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            view = self.flat[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev) if opt != "sgd" else None
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev) if opt != "sgd" else None
+        self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    # ---- torch.optim.Optimizer surface used by the trainer (trainer.py:207-222) --------------------------------------
+    def zero_grad(self):
+        self._check_views()
+        self.grad.zero_()
+
+    def step(self):
+        self._check_views()
+        lib = _lib.load()
+        self.t += 1
+        sq = None
+        if self.max_grad_norm is not None:
+            _lib.check(lib.cmf_grad_sqnorm(_p(self.grad), self.n, _p(self._ws), _p(self._sq), _stream()), "cmf_grad_sqnorm")
+            sq = self._sq
+        _lib.check(lib.cmf_optimizer_step(KINDS[self.opt], _p(self.flat), _p(self.grad), _p(self.m), _p(self.v), self.n,
+                                          self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
+                                          _p(sq), float(self.max_grad_norm or 0.), _stream()), "cmf_optimizer_step")
+
+    def grad_norm(self):
+        """Global gradient 2-norm as a device scalar (what ``clip_grad_norm_`` returns)."""
+        _lib.check(_lib.load().cmf_grad_sqnorm(_p(self.grad), self.n, _p(self._ws), _p(self._sq), _stream()), "cmf_grad_sqnorm")
+        return self._sq.sqrt()[0]
+
+    def allreduce_flat(self, average=True):
+        """Data-parallel gradient reduction: the flat gradient buffer IS the bucket."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+            if average:
+                self.grad.mul_(1.0 / dist.get_world_size())
+
+    def _check_views(self):
+        # autograd may REPLACE p.grad (e.g. after `p.grad = None`); fold such gradients back into the flat buffer
+        for p, o in zip(self.params, self.offsets):
+            view = self.grad[o:o + p.numel()]
+            if p.grad is None:
+                p.grad = view.view(p.shape)
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad.reshape(-1))
+                p.grad = view.view(p.shape)
+            if p.data.data_ptr() != self.flat.data_ptr() + 4 * o:
+                raise RuntimeError("a parameter was re-allocated after FlatOptimizer took ownership of its storage")
+
+    # ---- checkpoint schema of torch.optim (trainer.py:362-400 stores opt.state_dict()) -------------------------------
+    def state_dict(self):
+        state = {}
+        if self.t > 0 and self.opt != "sgd":
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                sl = slice(o, o + p.numel())
+                state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[sl].view(p.shape).clone(),
+                            _SECOND[self.opt]: self.v[sl].view(p.shape).clone()}
+        group = {"lr": self.lr, "weight_decay": self.weight_decay, "params": list(range(len(self.params)))}
+        if self.opt != "sgd":
+            group.update(betas=tuple(self.betas), eps=self.eps)
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(self.params):
+            raise ValueError("loaded state dict has a different number of parameters")
+        self.lr, self.weight_decay = float(group["lr"]), float(group.get("weight_decay", 0.))
+        if self.opt != "sgd":
+            self.betas, self.eps = tuple(group.get("betas", self.betas)), float(group.get("eps", self.eps))
+            self.m.zero_(), self.v.zero_()
+            steps = set()
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                st = sd["state"].get(i, sd["state"].get(group["params"][i]))
+                if st is None:
+                    continue
+                sl = slice(o, o + p.numel())
+                self.m[sl].copy_(st["exp_avg"].reshape(-1))
+                self.v[sl].copy_(st[_SECOND[self.opt]].reshape(-1))
+                steps.add(int(st["step"]))
+            if len(steps) > 1:
+                raise ValueError("per-parameter step counts differ: not representable in the flat optimiser")
+            self.t = steps.pop() if steps else 0

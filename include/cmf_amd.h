@@ -219,6 +219,22 @@ int cmf_elbo_combine(const float* low, const float* logdet, const float* rec, co
 int cmf_hutch_cg(const float* jtj, const float* eps, int d, int S, int B, int max_iter, int min_iter, float tol,
                  float* u, float* w, float* val, int* iters, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused optimiser step over one flat fp32 buffer: replaces the per-parameter loop of
+ * torch.optim.{SGD, Adam, Adamax}(params, lr, weight_decay).step() (experiment.py:515-534) and
+ * torch.nn.utils.clip_grad_norm_ (trainer.py:218-219).  `step` counts from 1.                      */
+#define CMF_OPT_SGD 0
+#define CMF_OPT_ADAM 1
+#define CMF_OPT_ADAMAX 2
+/* out[0] = sum g^2 (deterministic two-level reduction); ws: 1024 floats of caller-owned workspace   */
+int cmf_grad_sqnorm(const float* g, long long n, float* ws, float* out, void* stream);
+/* p, g, m, v: n floats each, 16-byte aligned (m, v unused for SGD).  sqnorm != NULL: the gradient is first
+ * scaled IN PLACE by min(1, max_norm / (sqrt(sqnorm[0]) + 1e-6)) -- read on the device, no host sync.
+ * Hyper-parameters are doubles: torch rounds 1 - beta and lr / (1 - beta^t) to fp32 only after forming them.  */
+int cmf_optimizer_step(int kind, float* p, float* g, float* m, float* v, long long n, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, int step, const float* sqnorm, float max_norm,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
