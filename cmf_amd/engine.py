@@ -239,6 +239,36 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
                4.0 * px * (cin + cout + (cout if res_t is not None else 0)), launch)
 
 
+_WGRAD_WS = {}
+
+
+def conv_tangent_wgrad(x_t, x_off, x_np, x_ci, x_px, gy_t, gy_off, y_np, y_co, y_px, dw, taps, np_, cin, cout, H, W, nc,
+                       fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, f_group=1, x_sl=16, y_sl=16):
+    """dw (cout, cin, kh, kw) += weight gradient of the tangent conv described like ``conv_tangent``'s forward launch;
+    ``gy_t`` (+ ``gy_off`` elements) is the cotangent of y with y's strides.  fp32 factor tensors only."""
+    lib = _lib.load()
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * cin * taps
+    a = ConvTangentArgs()
+    a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
+    a.f = _p(f); a.f_np, a.f_ci, a.f_px = int(f_np), int(f_ci), int(f_px); a.fmode = fmode
+    a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
+    a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), int(taps)
+    a.f_group = int(f_group)
+    a.x_sl, a.y_sl = int(x_sl), int(y_sl)
+    need = int(lib.cmf_conv_tangent_wgrad_ws(C.byref(a)))
+    key = (x_t.device, torch.cuda.current_stream().cuda_stream)      # one workspace per device and stream (re-entrant)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _WGRAD_WS[key] = torch.empty(need // 4, dtype=torch.float32, device=x_t.device)
+    gy = C.c_void_p(gy_t.data_ptr() + 4 * int(gy_off))
+    launch = lambda: _lib.check(lib.cmf_conv_tangent_wgrad(C.byref(a), gy, _p(dw), _p(ws), need, _stream()),
+                                "cmf_conv_tangent_wgrad")
+    if TIMER is None:
+        return launch()
+    px = float(H) * W * nc * np_
+    TIMER.wrap(f"conv_wgrad_t{taps}_ci{cin}_co{cout}", 2.0 * cin * cout * taps * px, 4.0 * px * (cin + cout), launch)
+
+
 def primal_regroup(t, to_grouped):
     """(B, N) <-> (B/16, N, 16): sample-grouped layout used to run primal data through the tangent kernels."""
     B = t.shape[0] if to_grouped else t.shape[0] * 16

@@ -104,6 +104,17 @@ int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
 int cmf_pack_weight_bf16x3(const float* w, void* out, int cout, int cin, long long* out_bytes, void* stream);
 int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* a, void* stream);
 
+/* Weight gradient of the tangent convolution (training; the reference gets it from autograd through
+ * get_conv2d_jvp / get_linear_jvp, jvp_layers.py:49-64, under loss.backward(), trainer.py:213):
+ *     dw[co][ci][tap] += sum_{np, px, col} gy(np, co, px, col) * F(np, ci, px+tap) * x(np, ci, px+tap, col)
+ * `a` describes the FORWARD launch: x, f, fmode (NONE / RELU / TANH / RAW), f_group, np, cin, cout, H, W, nc, taps and the
+ * strides are read from it; gy is the cotangent of y and is addressed like y (y_np, y_co, y_px, y_sl); a->w, y, r, bias,
+ * fo and mask_out are ignored.  dw: [cout][cin][taps] fp32 (the nn.Conv2d / nn.Linear weight layout), accumulated into.
+ * ws: caller-owned workspace of cmf_conv_tangent_wgrad_ws(a) bytes (partial sums, reduced in a fixed order).         */
+long long cmf_conv_tangent_wgrad_ws(const cmf_conv_tangent_args* a);
+int cmf_conv_tangent_wgrad(const cmf_conv_tangent_args* a, const float* gy, float* dw, float* ws, long long ws_bytes,
+                           void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Primal convolution / linear layer on fp32 MFMA: nn.Conv2d / nn.Linear forward of the coupler
  * networks (networks.py:50-60, :103-106, :206-224) with the preceding activation fused on load and

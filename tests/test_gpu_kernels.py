@@ -63,6 +63,45 @@ def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, monke
     assert rel(y, want) < 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,H,W,taps,nc", [
+    (64, 64, 14, 14, 9, 32), (64, 64, 6, 7, 9, 64), (2, 64, 14, 14, 9, 16), (1, 64, 8, 8, 9, 16), (64, 4, 14, 14, 1, 32),
+    (128, 64, 4, 14, 9, 16), (96, 130, 3, 5, 9, 16), (17, 40, 5, 7, 9, 32), (130, 70, 1, 37, 1, 16), (10, 128, 1, 50, 1, 16),
+])
+@pytest.mark.parametrize("fmode", ["none", "relu", "tanh"])
+@pytest.mark.parametrize("layout", ["panel", "slice"])
+def test_conv_tangent_weight_gradient(cin, cout, H, W, taps, nc, fmode, layout):
+    """dW of  <gy, conv(F x)>  against torch.autograd in float64; accumulates into an existing gradient."""
+    from cmf_amd import engine as E
+    if layout == "slice" and cin not in (64, 2, 128, 17):
+        pytest.skip("slice-major layout: a subset of the shapes is enough")
+    gen = torch.Generator().manual_seed(cin * 1000 + cout + H)
+    B, HW, k = 3, H * W, 3 if taps == 9 else 1
+    x = torch.randn(B, cin, H, W, nc, generator=gen)
+    gy = torch.randn(B, cout, H, W, nc, generator=gen)
+    prim = torch.randn(B, cin, H, W, generator=gen)
+    fac = {"none": torch.ones_like(prim), "relu": (prim > 0).float(), "tanh": 1 - torch.tanh(prim) ** 2}[fmode]
+    src = {"none": None, "relu": prim, "tanh": torch.tanh(prim)}[fmode]
+    w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    xin = (x * fac.unsqueeze(-1)).permute(0, 4, 1, 2, 3).reshape(B * nc, cin, H, W).double()
+    y = F.conv2d(xin, w, padding=1 if taps == 9 else 0)
+    (y * gy.permute(0, 4, 1, 2, 3).reshape(B * nc, cout, H, W).double()).sum().backward()
+    if layout == "panel":
+        to_dev = lambda t: t.cuda()
+        st = lambda c: (c * HW * nc, HW * nc, nc)
+        sl = lambda c: 16
+    else:
+        S = nc // 16
+        to_dev = lambda t: t.reshape(B, -1, HW, S, 16).permute(0, 2, 3, 1, 4).contiguous().cuda()
+        st = lambda c: (c * HW * nc, 16, c * nc)
+        sl = lambda c: c * 16
+    prev = torch.randn(cout, cin, k, k, generator=gen)
+    dw = prev.clone().cuda()
+    E.conv_tangent_wgrad(to_dev(x), 0, *st(cin), to_dev(gy), 0, *st(cout), dw, taps, B, cin, cout, H, W, nc,
+                         fmode={"none": E.F_NONE, "relu": E.F_RELU, "tanh": E.F_TANH}[fmode],
+                         f=None if src is None else src.cuda(), f_np=cin * HW, f_ci=HW, f_px=1, x_sl=sl(cin), y_sl=sl(cout))
+    assert rel(dw.cpu() - prev, w.grad) < 2e-5
+
+
 @pytest.mark.parametrize("cin,cout,H,W,taps", [(64, 64, 28, 28, 9), (1, 64, 28, 28, 9), (64, 2, 28, 28, 1), (2, 64, 14, 14, 9),
                                                (3, 64, 32, 32, 9), (64, 24, 16, 16, 1), (5, 33, 7, 19, 9), (70, 130, 1, 300, 1)])
 @pytest.mark.parametrize("imode", ["none", "relu", "raw"])

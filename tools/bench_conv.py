@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None); ap.add_argument("--B", type=int, default=128); ap.add_argument("--hw", type=int, default=28)
 ap.add_argument("--res", type=int, default=1); ap.add_argument("--precision", default="bf16x3"); ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--fmode", default="relu"); ap.add_argument("--nc", type=int, default=64)
+ap.add_argument("--wgrad", action="store_true", help="time cmf_conv_tangent_wgrad (weight gradient) instead of the forward conv")
 ap.add_argument("--layout", default="slice", help="slice = [px][slice][ch][16] hidden layout, panel = [ch][px][nc]")
 args = ap.parse_args()
 from cmf_amd import _lib
@@ -22,12 +23,18 @@ B, H, nc, ch = args.B, args.hw, args.nc, 64
 HW = H * H
 x = torch.randn(B, ch, H, H, nc, device="cuda"); prim = torch.randn(B, ch, H, H, device="cuda")
 res = torch.randn(B, ch, H, H, nc, device="cuda") if args.res else None
-y = torch.empty(B, ch, H, H, nc, device="cuda")
+y = torch.randn(B, ch, H, H, nc, device="cuda") if args.wgrad else torch.empty(B, ch, H, H, nc, device="cuda")
 w = torch.nn.Parameter(torch.randn(ch, ch, 3, 3, device="cuda") / 24)
 fm = {"relu": E.F_RELU, "none": E.F_NONE}[args.fmode]
 st = (ch * HW * nc, 16, ch * nc) if args.layout == "slice" else (ch * HW * nc, HW * nc, nc)
 sl = ch * 16 if args.layout == "slice" else 16
+dw = torch.zeros(ch, ch, 3, 3, device="cuda")
+def run_wgrad():
+    E.conv_tangent_wgrad(x, 0, *st, y, 0, *st, dw, 9, B, ch, ch, H, H, nc, fmode=fm, f=prim if fm else None, f_np=ch * HW, f_ci=HW,
+                         f_px=1, x_sl=sl, y_sl=sl)
 def run():
+    if args.wgrad:
+        return run_wgrad()
     E.conv_tangent(x, 0, *st, w, 9, y, *st, B, ch, ch, H, H, nc, fmode=fm,
                    f=prim if fm else None, f_np=ch * HW, f_ci=HW, f_px=1, res_t=res, x_sl=sl, y_sl=sl)
 for _ in range(3): run()
@@ -38,5 +45,5 @@ for _ in range(args.iters): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.iters
 fl = 2.0 * ch * ch * 9 * HW * nc * B
-print(f"{os.path.basename(args.lib or 'libcmf_amd.so'):28s} B={B} {H}x{H} res={args.res} {args.precision} {args.layout}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s  "
+print(f"{os.path.basename(args.lib or 'libcmf_amd.so'):28s} B={B} {H}x{H} res={args.res} {'wgrad f32' if args.wgrad else args.precision} {args.layout}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s  "
       f"{4.0*HW*nc*B*ch*(2+args.res)/ms/1e6:7.1f} GB/s")
