@@ -16,6 +16,8 @@
 // input pixel from L1 / L2).  Partial blocks go to a workspace and a second kernel sums them in a fixed order and
 // accumulates into dW (deterministic; no float atomics).  Larger cout / cin are tiled by the host over 64 x 64 blocks.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -122,6 +124,163 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(cmf_conv_tangent_arg
   }
 }
 
+// 3x3 with a sliding window.  The simple kernel above issues 19 sixteen-byte loads per K block and wave, nine of them
+// for pixels the same wave loaded one and two steps earlier.  Here wave w owns output-channel tile w & 3 and
+// input-channel tiles {2 (w >> 2), 2 (w >> 2) + 1} for ALL nine taps, walks along image rows, and keeps four image
+// columns (3 rows x 2 channel tiles each) in a register ring: per step ONE new column (6 loads + 6 factor words) and one
+// gy quad are fetched, one step (72 MFMAs) ahead of their first use.  An image row is a stream of W + 2
+// column slots (the zero-padding columns included, as zeros), rows follow each other without a pipeline restart, and
+// everything is branch-free: validity is a select on the loaded values.
+struct WCol {
+  f32x4 v[2][3];                                                   // [ci tile][row dy]
+  float f[2][3];
+};
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad3x3_kernel(cmf_conv_tangent_args a, const float* __restrict__ gy,
+                                                               float* __restrict__ ws, int co0, int ci0, int nrows) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = wave & 3, h = wave >> 2;
+  const int r = lane & 15, q = lane >> 4;
+  const int W = a.W, H = a.H, nsl = a.nc / 16;
+  const long long xsl = a.x_sl ? a.x_sl : 16, ysl = a.y_sl ? a.y_sl : 16;
+  const int fgrp = a.f_group > 1 ? a.f_group : 1;
+  const bool has_f = a.f != nullptr && a.fmode != CMF_F_NONE;
+  // factor = c0 + c1 [f > 0] + c2 f + c3 f^2  (NONE: 1, RELU: [f > 0], TANH: 1 - f^2, RAW: f) -- branch-free
+  const float fc0 = (!has_f || a.fmode == CMF_F_TANH) ? 1.f : 0.f, fc1 = (has_f && a.fmode == CMF_F_RELU) ? 1.f : 0.f;
+  const float fc2 = (has_f && a.fmode == CMF_F_RAW) ? 1.f : 0.f, fc3 = (has_f && a.fmode == CMF_F_TANH) ? -1.f : 0.f;
+
+  const int co = co0 + c * 16 + r;
+  const long long gy_lane = (long long)(co < a.cout ? co : a.cout - 1) * a.y_co + 4 * q;
+  long long x_lane[2], f_lane[2];
+  bool ci_ok[2];
+#pragma unroll
+  for (int il = 0; il < 2; ++il) {
+    const int ci = ci0 + (2 * h + il) * 16 + r, cic = ci < a.cin ? ci : a.cin - 1;
+    ci_ok[il] = ci < a.cin;
+    x_lane[il] = (long long)cic * a.x_ci + 4 * q;
+    f_lane[il] = (long long)cic * a.f_ci;
+  }
+
+  f32x4 acc[2][9];
+#pragma unroll
+  for (int il = 0; il < 2; ++il)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[il][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this workgroup's image rows (row id = (sample * H + y) * nsl + slice) and its slot stream
+  const int per = (nrows + gridDim.x - 1) / gridDim.x;
+  const int row0 = blockIdx.x * per, row1 = row0 + per < nrows ? row0 + per : nrows;
+  const int nslots = row1 > row0 ? (row1 - row0) * (W + 2) : 0;
+
+  // load cursor: the slot the next fetch brings in
+  int l_slot = 0, l_col = -1, l_sl = 0, l_yy = 0, l_n = 0;
+  if (row1 > row0) {
+    l_sl = row0 % nsl;
+    const int t = row0 / nsl;
+    l_yy = t % H;
+    l_n = t / H;
+  }
+  WCol ring[4];
+  f32x4 gring[4];
+  int okrow[4], okg[4];                                            // wave-uniform validity bits of the ring entries
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    okrow[i] = okg[i] = 0;
+    gring[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int il = 0; il < 2; ++il)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) ring[i].v[il][dy] = f32x4{0.f, 0.f, 0.f, 0.f}, ring[i].f[il][dy] = 0.f;
+  }
+
+  auto fetch = [&](WCol& cs, f32x4& g, int& rowbits, int& gbit) __attribute__((always_inline)) {
+    const bool alive = l_slot < nslots;
+    const bool colok = alive && l_col >= 0 && l_col < W;
+    const int colc = l_col < 0 ? 0 : l_col >= W ? W - 1 : l_col;
+    const float* xb = a.x + (long long)l_n * a.x_np + l_sl * xsl;
+    const float* fb = has_f ? a.f + (long long)(l_n / fgrp) * a.f_np + (l_n % fgrp) : a.x;
+    rowbits = 0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y2 = l_yy + dy - 1;
+      const bool rok = colok && y2 >= 0 && y2 < H;
+      const int p2 = (y2 < 0 ? 0 : y2 >= H ? H - 1 : y2) * W + colc;
+      rowbits |= rok ? 1 << dy : 0;
+#pragma unroll
+      for (int il = 0; il < 2; ++il) {
+        cs.v[il][dy] = *reinterpret_cast<const f32x4*>(xb + (long long)p2 * a.x_px + x_lane[il]);
+        cs.f[il][dy] = fb[has_f ? (long long)p2 * a.f_px + f_lane[il] : 0];   // !has_f: any finite word (fc1..3 = 0)
+      }
+    }
+    g = *reinterpret_cast<const f32x4*>(gy + (long long)l_n * a.y_np + (long long)(l_yy * W + colc) * a.y_px + l_sl * ysl + gy_lane);
+    gbit = colok ? 1 : 0;
+    // advance (branch-free, SALU selects); past the end the cursor stays on the last slot, whose addresses are valid
+    const int more = (alive && l_slot + 1 < nslots) ? 1 : 0;
+    l_slot += alive ? 1 : 0;
+    const int wrap_c = more && l_col == W;
+    l_col = wrap_c ? -1 : l_col + more;
+    const int wrap_s = wrap_c && l_sl + 1 == nsl;
+    l_sl = wrap_s ? 0 : l_sl + wrap_c;
+    const int wrap_y = wrap_s && l_yy + 1 == H;
+    l_yy = wrap_y ? 0 : l_yy + wrap_s;
+    l_n += wrap_y;
+  };
+  auto settle = [&](WCol& cs, f32x4& g, int rowbits, int gbit) __attribute__((always_inline)) {   // first use: factor + validity
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int il = 0; il < 2; ++il) {
+        const bool ok = ((rowbits >> dy) & 1) && ci_ok[il];
+        const float f = cs.f[il][dy];
+        const float m = fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cs.v[il][dy][k] = ok ? cs.v[il][dy][k] * m : 0.f;
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = gbit ? g[k] : 0.f;
+  };
+
+  if (nslots > 0) {
+    fetch(ring[0], gring[0], okrow[0], okg[0]);
+    fetch(ring[1], gring[1], okrow[1], okg[1]);
+    settle(ring[0], gring[0], okrow[0], okg[0]);
+  }
+  // step i of an unrolled group: centre = ring[i], left = ring[i-1], right = ring[i+1] (settled here), fetch into ring[i+2]
+  auto step = [&](auto I) __attribute__((always_inline)) {
+    constexpr int i = decltype(I)::value;
+    constexpr int L = (i + 3) % 4, R = (i + 1) % 4, N = (i + 2) % 4;
+    settle(ring[R], gring[R], okrow[R], okg[R]);                   // waits for the fetch of the PREVIOUS step ...
+    fetch(ring[N], gring[N], okrow[N], okg[N]);                    // ... before this one is issued: it flies during the MFMAs
+    const f32x4 g = gring[i];
+#pragma unroll
+    for (int il = 0; il < 2; ++il)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[il][dy * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[k], ring[L].v[il][dy][k], acc[il][dy * 3 + 0], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[il][dy * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[k], ring[i].v[il][dy][k], acc[il][dy * 3 + 1], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[il][dy * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[k], ring[R].v[il][dy][k], acc[il][dy * 3 + 2], 0, 0, 0);
+      }
+  };
+  for (int s = 0; s < nslots; s += 4) {                            // slots past the end are dead (all-zero operands)
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+  }
+
+  float* out = ws + (size_t)blockIdx.x * 64 * 64 * 9;
+#pragma unroll
+  for (int il = 0; il < 2; ++il)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[((c * 16 + 4 * q + i) * 64 + (2 * h + il) * 16 + r) * 9 + t] = acc[il][t][i];
+}
+
 // dw[(co0 + co)][ci0 + ci][tap] += sum_wg ws[wg][co][ci][tap]   (fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nwg,
                                                            int taps, int co0, int ci0, int cout, int cin) {
@@ -153,11 +312,16 @@ extern "C" int cmf_conv_tangent_wgrad(const cmf_conv_tangent_args* a, const floa
   if (((uintptr_t)a->x | (uintptr_t)gy) % 16 || (a->x_np | a->x_ci | a->x_px | a->x_sl | a->y_np | a->y_co | a->y_px | a->y_sl) % 4)
     return CMF_EINVAL;
   const long long nkb = (long long)a->np * a->H * a->W * (a->nc / 16);
-  const int grid = (int)(nkb < WG_MAX ? nkb : WG_MAX);
+  const long long nrows = (long long)a->np * a->H * (a->nc / 16);
+  if (nrows > 0x7fffffffLL / (a->W + 2)) return CMF_ERANGE;
+  static const bool simple = getenv("CMF_WGRAD_SIMPLE") != nullptr;    // diagnostic: the one-K-block-per-step kernel for 3x3 too
+  const long long units = (a->taps == 9 && !simple) ? nrows : nkb;
+  const int grid = (int)(units < WG_MAX ? units : WG_MAX);
   hipStream_t s = (hipStream_t)stream;
   for (int co0 = 0; co0 < a->cout; co0 += 64)
     for (int ci0 = 0; ci0 < a->cin; ci0 += 64) {
-      if (a->taps == 9) hipLaunchKernelGGL(conv_wgrad_kernel<9>, dim3(grid), dim3(512), 0, s, *a, gy, ws, co0, ci0, nkb);
+      if (a->taps == 9 && !simple) hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3(grid), dim3(512), 0, s, *a, gy, ws, co0, ci0, (int)nrows);
+      else if (a->taps == 9) hipLaunchKernelGGL(conv_wgrad_kernel<9>, dim3(grid), dim3(512), 0, s, *a, gy, ws, co0, ci0, nkb);
       else hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(512), 0, s, *a, gy, ws, co0, ci0, nkb);
       CMF_LAUNCH_CHECK();
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cmf_ceil_div(64 * 64 * a->taps, 256)), dim3(256), 0, s, ws, dw, grid,
