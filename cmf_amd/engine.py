@@ -570,10 +570,27 @@ def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts
     return y, g, [a0] + [std_of(t) for t in acts[1:]]
 
 
-def net_tangent(net, T, view, acts, transpose_packs=False):
+def _view_rows(T, view):
+    """Compact copy of the rows of ``T`` a coupler network reads (``view``): cin channels, in T's layout."""
+    if T.layout == "panel":
+        HW = view.geom.HW
+        rows = T.data[: T.B * T.N * T.nc].view(T.B, T.N // HW, HW * T.nc)[:, view.chan_off::view.chan_step][:, :view.cin]
+        out = Tangent(T.B, view.cin * HW, T.nc, "panel", T.data.device)
+    else:
+        rows = T.data[: T.B * T.N * T.nc].view(T.N, T.B * T.nc)[view.chan_off::view.chan_step][:view.cin]
+        out = Tangent(T.B, view.cin, T.nc, "fmajor", T.data.device)
+    out.data.view(rows.shape).copy_(rows)
+    return out
+
+
+def net_tangent(net, T, view, acts, transpose_packs=False, save=None):
     """Push all Jacobian columns of ``T`` through the coupler network; returns the raw tangent of the
-    network's pre-activation output (the ScaledTanh derivative ``g`` is applied by acl_tangent)."""
+    network's pre-activation output (the ScaledTanh derivative ``g`` is applied by acl_tangent).
+    ``save`` (a list, training): the input tangent of every conv / linear layer is kept and appended, in forward order
+    (the network's own input as a compact copy of the rows it reads), for ``net_cotangent(..., saved=, grads=)``."""
     geo, B, nc, dev = view.geom, T.B, T.nc, T.data.device
+    if save is not None:
+        save.append(_view_rows(T, view))
     if net.kind == "resnet":
         conv0, blocks, convf = _resnet_parts(net)
         hid, cout, H, W, HW = conv0.out_channels, convf.out_channels, geo.H, geo.W, geo.HW
@@ -599,7 +616,13 @@ def net_tangent(net, T, view, acts, transpose_packs=False):
             conv_tangent(h.data, 0, *hd, blk.conv1.weight, 9, u.data, *hd, B, hid, hid, H, W, nc, x_sl=hsl, y_sl=hsl, **fk(a_in))
             conv_tangent(u.data, 0, *hd, blk.conv2.weight, 9, h2.data, *hd, B, hid, hid, H, W, nc, res_t=h.data, x_sl=hsl,
                          y_sl=hsl, **fk(c1))
-            h, h2 = h2, h
+            if save is not None:                              # keep h_k and u_k: no ping-pong reuse
+                save += [h, u]
+                h, u, h2 = h2, new(hid), new(hid)
+            else:
+                h, h2 = h2, h
+        if save is not None:
+            save.append(h)
         yt = new(cout)
         conv_tangent(h.data, 0, *hd, convf.weight, 1, yt.data, *pn(cout), B, hid, cout, H, W, nc, fmode=F_RELU,
                      f=acts[-1], x_sl=hsl, **fs)
@@ -615,56 +638,91 @@ def net_tangent(net, T, view, acts, transpose_packs=False):
         if i < len(acts):
             fmode, f, f_px = F_TANH, acts[i], lin.out_features
         x_t, x_off, x_ci, cin = out.data, 0, B * nc, lin.out_features
+        if save is not None and i + 1 < len(lins):
+            save.append(out)
     return out
 
 
-def net_cotangent(net, YC, view, acts, Ct):
+def _grad_of(grads, weight):
+    g = grads.get(weight)
+    if g is None:
+        g = grads[weight] = torch.zeros_like(weight, dtype=torch.float32).contiguous()
+    return g
+
+
+def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None):
     """Reverse sweep through the coupler network (the adjoint of ``net_tangent``): ``YC`` is the cotangent of the network's
     raw output; the cotangent of its input is ACCUMULATED into the rows of ``Ct`` the network reads (``view``).
     The adjoint of "factor, then conv" is "transposed conv, then factor": transposed / tap-flipped packs
-    (``cmf_pack_weight(transpose=1)``) and the OUTPUT-side factor of ``cmf_conv_tangent`` (fp32 MFMA kernel)."""
+    (``cmf_pack_weight(transpose=1)``) and the OUTPUT-side factor of ``cmf_conv_tangent`` (fp32 MFMA kernel), so every
+    stored tensor is the true cotangent of a layer output.
+    Training (``saved`` = the list ``net_tangent(save=)`` filled, ``grads`` = dict parameter -> gradient tensor): the weight
+    gradient of every layer, ``dW += sum c_out (x) F x_in`` (``cmf_conv_tangent_wgrad``), is accumulated into ``grads``.
+    Biases do not act on tangents and get no gradient here."""
     geo, B, nc, dev = view.geom, Ct.B, Ct.nc, Ct.data.device
     f32 = dict(transpose=True, precision="f32")
+    train = saved is not None
+    assert not train or grads is not None
     if net.kind == "resnet":
         conv0, blocks, convf = _resnet_parts(net)
         hid, cout, H, W, HW = conv0.out_channels, convf.out_channels, geo.H, geo.W, geo.HW
         assert getattr(acts, "f_group", 1) == 1, "the reverse sweep reads per-sample activations"
         new = lambda c: Tangent(B, c * HW, nc, "panel", dev)
         pn = lambda c: (c * HW * nc, HW * nc, nc)          # (np, chan, px) strides of a panel with c channels
+        hd, hsl = (hid * HW * nc, 16, hid * nc), hid * 16  # the forward pass's slice-major hidden layout (net_tangent)
         fa = dict(fo_np=hid * HW, fo_co=HW, fo_px=1, fomode=F_RELU)
+        fr = dict(fmode=F_RELU, f_np=hid * HW, f_ci=HW, f_px=1)
+        if train:
+            t_in, hs, us = saved[0], saved[1::2], saved[2::2]  # h_0 .. h_K, u_0 .. u_{K-1}
+            assert len(hs) == len(blocks) + 1 and len(us) == len(blocks)
+            # y = convf(relu'(a_last) . h_K)
+            conv_tangent_wgrad(hs[-1].data, 0, *hd, YC.data, 0, *pn(cout), _grad_of(grads, convf.weight), 1, B, hid, cout, H, W, nc,
+                               f=acts[-1], x_sl=hsl, **fr)
         # y = convf(relu'(a_last) . h)  ->  c_h = relu'(a_last) . convf^T(c_y)
         ch = new(hid)
         conv_tangent(YC.data, 0, *pn(cout), convf.weight, 1, ch.data, *pn(hid), B, cout, hid, H, W, nc, fo=acts[-1], **fa, **f32)
         u, ch2 = new(hid), new(hid)
         for k in reversed(range(len(blocks))):
             blk, a_in, c1 = blocks[k], acts[2 * k], acts[2 * k + 1]
-            # h2 = h + conv2(relu'(c1) . conv1(relu'(a_in) . h))  ->  c_h = c_h2 + relu'(a_in) . conv1^T(relu'(c1) . conv2^T(c_h2))
-            conv_tangent(ch.data, 0, *pn(hid), blk.conv2.weight, 9, u.data, *pn(hid), B, hid, hid, H, W, nc, **f32)
-            conv_tangent(u.data, 0, *pn(hid), blk.conv1.weight, 9, ch2.data, *pn(hid), B, hid, hid, H, W, nc, fmode=F_RELU, f=c1,
-                         f_np=hid * HW, f_ci=HW, f_px=1, res_t=ch.data, fo=a_in, **fa, **f32)
+            # h2 = h + conv2(relu'(c1) . u), u = conv1(relu'(a_in) . h):
+            #   c_u = relu'(c1) . conv2^T(c_h2);   c_h = c_h2 + relu'(a_in) . conv1^T(c_u)
+            if train:
+                conv_tangent_wgrad(us[k].data, 0, *hd, ch.data, 0, *pn(hid), _grad_of(grads, blk.conv2.weight), 9, B, hid, hid, H, W,
+                                   nc, f=c1, x_sl=hsl, **fr)
+            conv_tangent(ch.data, 0, *pn(hid), blk.conv2.weight, 9, u.data, *pn(hid), B, hid, hid, H, W, nc, fo=c1, **fa, **f32)
+            if train:
+                conv_tangent_wgrad(hs[k].data, 0, *hd, u.data, 0, *pn(hid), _grad_of(grads, blk.conv1.weight), 9, B, hid, hid, H, W,
+                                   nc, f=a_in, x_sl=hsl, **fr)
+            conv_tangent(u.data, 0, *pn(hid), blk.conv1.weight, 9, ch2.data, *pn(hid), B, hid, hid, H, W, nc, res_t=ch.data,
+                         fo=a_in, **fa, **f32)
             ch, ch2 = ch2, ch
         # h0 = conv0(mask . v_in)  ->  Ct[view] += mask . conv0^T(c_h0)
         off = view.chan_off * HW * nc
         m = view.mask
+        if train:
+            conv_tangent_wgrad(t_in.data, 0, *pn(view.cin), ch.data, 0, *pn(hid), _grad_of(grads, conv0.weight), 9, B, view.cin, hid,
+                               H, W, nc, fmode=F_RAW if m is not None else F_NONE, f=m, f_np=0, f_ci=HW, f_px=1)
         conv_tangent(ch.data, 0, *pn(hid), conv0.weight, 9, Ct.data, Ct.t_b, view.chan_step * HW * nc, nc, B, hid, view.cin, H, W, nc,
                      y_off=off, res_t=Ct.data, res_off=off, fo=m, fo_np=0, fo_co=HW, fo_px=1,
                      fomode=F_RAW if m is not None else F_NONE, **f32)
         return
     lins = [mod for mod in net if isinstance(mod, nn.Linear)]
-    # x_i = W_i (phi_{i-1} . x_{i-1}), phi_0 = 1, phi_i = tanh'(h_i):  c~_{i-1} = W_i^T (phi_i . c~_i) with the factor on the
-    # INPUT side of the next transposed layer; the chain ends unmasked, accumulated into the rows the network read
-    x_t, x_ci, cin = YC.data, B * nc, lins[-1].out_features
+    # x_i = W_i (phi_{i-1} . x_{i-1}), phi_0 = 1, phi_i = tanh'(h_i):  c_{i-1} = phi_{i-1} . W_i^T c_i  (output-side factor);
+    # the chain ends unmasked, accumulated into the rows the network read.  dW_i = sum c_i (x) phi_{i-1} x_{i-1}.
+    c_t, cin = YC.data, lins[-1].out_features
     for i in reversed(range(len(lins))):
         lin = lins[i]
-        last = i == 0
-        fmode, f, f_px = (F_TANH, acts[i], lin.out_features) if i < len(acts) and i < len(lins) - 1 else (F_NONE, None, 0)
-        if last:
+        if train:
+            xin = saved[i]
+            fm = dict(fmode=F_TANH, f=acts[i - 1], f_np=0, f_ci=1, f_px=lin.in_features) if i > 0 else {}
+            conv_tangent_wgrad(xin.data, 0, 0, B * nc, nc, c_t, 0, 0, B * nc, nc, _grad_of(grads, lin.weight), 1, 1, lin.in_features,
+                               lin.out_features, 1, B, nc, **fm)
+        if i == 0:
             off = view.chan_off * B * nc
-            conv_tangent(x_t, 0, 0, x_ci, nc, lin.weight, 1, Ct.data, 0, view.chan_step * B * nc, nc, 1, cin, view.cin, 1, B, nc,
-                         fmode=fmode, f=f, f_np=0, f_ci=1, f_px=f_px, y_off=off, res_t=Ct.data, res_off=off, **f32)
+            conv_tangent(c_t, 0, 0, B * nc, nc, lin.weight, 1, Ct.data, 0, view.chan_step * B * nc, nc, 1, cin, view.cin, 1, B, nc,
+                         y_off=off, res_t=Ct.data, res_off=off, **f32)
         else:
             out = Tangent(B, lin.in_features, nc, "fmajor", dev)
-            conv_tangent(x_t, 0, 0, x_ci, nc, lin.weight, 1, out.data, 0, B * nc, nc, 1, cin, lin.in_features, 1, B, nc,
-                         fmode=fmode, f=f, f_np=0, f_ci=1, f_px=f_px, **f32)
-            x_t, cin = out.data, lin.in_features
-
+            conv_tangent(c_t, 0, 0, B * nc, nc, lin.weight, 1, out.data, 0, B * nc, nc, 1, cin, lin.in_features, 1, B, nc,
+                         fo=acts[i - 1], fo_np=0, fo_co=1, fo_px=lin.in_features, fomode=F_TANH, **f32)
+            c_t, cin = out.data, lin.in_features
