@@ -106,6 +106,51 @@ __global__ void acl_cotangent_kernel(float* __restrict__ c, long long c_b, long 
   *cp = es * v;
 }
 
+// acl cross terms (training): the tangent update  out = es (v - zo gs sd) - gt td  also depends on PRIMAL quantities;
+// their cotangents are column reductions of c . d(out)/d(.) -- one wavefront per (sample, modified element):
+//   d s  = -sum_col c es (v - zo gs sd)     d zo = -sum_col c es gs sd
+//   d gs = -sum_col c es zo sd              d gt = -sum_col c td
+__global__ __launch_bounds__(256) void acl_cross_terms_kernel(const float* __restrict__ c, long long c_b, long long c_r,
+                                                              const float* __restrict__ v, long long v_b, long long v_r,
+                                                              const float* __restrict__ yt, long long yt_b, long long yt_r,
+                                                              int nc, const float* __restrict__ z, long long z_b,
+                                                              const float* __restrict__ y, long long y_b,
+                                                              const float* __restrict__ g, const int* __restrict__ zi,
+                                                              const int* __restrict__ si, const int* __restrict__ ti, int n_mod,
+                                                              long long n_rows, float* __restrict__ dz,
+                                                              float* __restrict__ dy, float* __restrict__ dg) {
+  const long long be = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (be >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int e = (int)(be % n_mod);
+  const long long b = be / n_mod;
+  const int rs = si[e], rt = ti[e], rz = zi[e];
+  const float s = y[b * y_b + rs], zo = z[b * z_b + rz];
+  const float gs = g ? g[b * y_b + rs] : 1.f;
+  const float es = expf(-s);
+  const float* cp = c + b * c_b + (long long)rz * c_r;
+  const float* vp = v + b * v_b + (long long)e * v_r;
+  const float* sp = yt + b * yt_b + (long long)rs * yt_r;
+  const float* tp = yt + b * yt_b + (long long)rt * yt_r;
+  float a_s = 0.f, a_z = 0.f, a_gs = 0.f, a_gt = 0.f;
+  for (int k = lane; k < nc; k += 64) {
+    const float cv = cp[k], sd = sp[k];
+    a_s -= cv * es * (vp[k] - zo * gs * sd);
+    a_z -= cv * es * gs * sd;
+    a_gs -= cv * es * zo * sd;
+    a_gt -= cv * tp[k];
+  }
+  a_s = wave_sum(a_s), a_z = wave_sum(a_z), a_gs = wave_sum(a_gs), a_gt = wave_sum(a_gt);
+  if (lane == 0) {
+    dy[b * y_b + rs] += a_s;
+    dz[b * z_b + rz] += a_z;
+    if (dg) {
+      dg[b * y_b + rs] += a_gs;
+      dg[b * y_b + rt] += a_gt;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void gather_primal_kernel(const float* __restrict__ in, long long in_b, float* __restrict__ out,
                                      long long out_b, const int* __restrict__ idx, int n_out, long long total) {
@@ -315,6 +360,19 @@ int cmf_acl_cotangent(float* c, long long c_b, long long c_r, float* yc, long lo
   const long long total = (long long)B * n_mod * (nc / 4);
   hipLaunchKernelGGL(acl_cotangent_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, c, c_b, c_r, yc, yc_b,
                      yc_r, nc / 4, z, z_b, y, y_b, g, zi, si, ti, n_mod, total);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+int cmf_acl_cross_terms(const float* c, long long c_b, long long c_r, const float* v, long long v_b, long long v_r,
+                        const float* yt, long long yt_b, long long yt_r, int nc, const float* z, long long z_b,
+                        const float* y, long long y_b, const float* g, const int* zi, const int* si, const int* ti,
+                        int n_mod, int B, float* dz, float* dy, float* dg, void* stream) {
+  if (!c || !v || !yt || !z || !y || !zi || !si || !ti || !dz || !dy || n_mod <= 0 || B <= 0 || nc <= 0) return CMF_EINVAL;
+  if ((g == nullptr) != (dg == nullptr)) return CMF_EINVAL;
+  const long long n_rows = (long long)B * n_mod;
+  hipLaunchKernelGGL(acl_cross_terms_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, c, c_b, c_r, v, v_b, v_r,
+                     yt, yt_b, yt_r, nc, z, z_b, y, y_b, g, zi, si, ti, n_mod, n_rows, dz, dy, dg);
   CMF_LAUNCH_CHECK();
   return 0;
 }

@@ -334,6 +334,26 @@ def acl_cotangent(Ct, YC, z, y, g, maps):
                                              _p(maps["ti"]), maps["n"], B, _stream()), "cmf_acl_cotangent")
 
 
+def modified_rows(T, maps):
+    """Compact copy (B, n_mod, nc) of the rows of ``T`` a coupling layer is about to update (kept for acl_cross_terms)."""
+    out = Tangent(T.B, maps["n"], T.nc, T.layout, T.data.device)
+    _lib.check(_lib.load().cmf_gather_tangent(_p(T.data), T.t_b, T.t_r, _p(out.data), out.t_b, out.t_r, _p(maps["zi"]), maps["n"],
+                                              T.nc, T.B, _stream()), "cmf_gather_tangent")
+    return out
+
+
+def acl_cross_terms(Ct, V, YT, z, y, g, maps, dz, dy, dg):
+    """Primal cotangents of the tangent update (training): column reductions accumulated into ``dz`` (like z), ``dy`` (like y:
+    the log-scale entries) and ``dg`` (like g).  ``Ct`` must still hold the cotangent of the UPDATED rows: call this before
+    ``acl_cotangent``.  ``V`` = ``modified_rows(T, maps)`` taken before ``acl_tangent``, ``YT`` = the network's raw tangent."""
+    B = z.shape[0]
+    z2, y2 = z.view(B, -1), y.view(B, -1)
+    _lib.check(_lib.load().cmf_acl_cross_terms(_p(Ct.data), Ct.t_b, Ct.t_r, _p(V.data), V.t_b, V.t_r, _p(YT.data), YT.t_b, YT.t_r,
+                                               Ct.nc, _p(z2), z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]),
+                                               _p(maps["si"]), _p(maps["ti"]), maps["n"], B, _p(dz), _p(dy), _p(dg), _stream()),
+               "cmf_acl_cross_terms")
+
+
 class GramResult:
     __slots__ = ("jtj", "logdet", "l1_off", "l1_diag", "info", "fail", "attempts")
 

@@ -161,6 +161,16 @@ int cmf_acl_primal(float* z, long long z_b, const float* y, long long y_b, const
 int cmf_acl_cotangent(float* c, long long c_b, long long c_r, float* yc, long long yc_b, long long yc_r, int nc,
                       const float* z, long long z_b, const float* y, long long y_b, const float* g, const int* zi,
                       const int* si, const int* ti, int n_mod, int B, void* stream);
+/* Cross terms of the coupling update for training (autograd through acl.py:48-66, :113-146 in the reference): the tangent
+ * update  out(b, zi[e], :) = es (v - zo gs sd) - gt td  of cmf_acl_tangent also depends on primal values.  Given the
+ * cotangent c of `out` (rows zi[e], BEFORE cmf_acl_cotangent rewrites them), the saved input rows v (compact: row e at
+ * v + b*v_b + e*v_r) and the network's raw tangent yt, accumulates (+=) the column reductions
+ *   dy[b][si[e]] += d/ds,   dz[b][zi[e]] += d/d zo,   dg[b][si[e]] += d/d gs,   dg[b][ti[e]] += d/d gt
+ * (dg and g both NULL for networks without the ScaledTanh output stage).                                     */
+int cmf_acl_cross_terms(const float* c, long long c_b, long long c_r, const float* v, long long v_b, long long v_r,
+                        const float* yt, long long yt_b, long long yt_r, int nc, const float* z, long long z_b,
+                        const float* y, long long y_b, const float* g, const int* zi, const int* si, const int* ti,
+                        int n_mod, int B, float* dz, float* dy, float* dg, void* stream);
 int cmf_acl_tangent(float* t, long long t_b, long long t_r, const float* yt, long long yt_b, long long yt_r,
                     int nc, const float* z, long long z_b, const float* y, long long y_b, const float* g,
                     const int* zi, const int* si, const int* ti, int n_mod, int B, void* stream);

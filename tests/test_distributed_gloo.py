@@ -89,7 +89,9 @@ def _grad_worker(rank, world, port, q):
         if rank == 1:
             net[2].bias.grad = None                  # a parameter without a gradient on one rank
         nb = allreduce_gradients(list(net.parameters()) + [frozen], bucket_bytes=64)     # tiny buckets: several of them
-        q.put((rank, nb, [p.grad.clone() for p in net.parameters()]))
+        # plain numpy through the queue: torch tensors travel as file descriptors the parent has to fetch from THIS process,
+        # which fails (ConnectionResetError) when the worker has already exited
+        q.put((rank, nb, [p.grad.numpy().copy() for p in net.parameters()]))
     finally:
         dist.destroy_process_group()
 
@@ -118,5 +120,5 @@ def test_allreduce_gradients_matches_full_batch():
     assert res[0][1] == res[1][1] and res[0][1] > 1
     for r in range(2):
         for got, w in zip(res[r][2], want):
-            assert torch.allclose(got, w, rtol=1e-6, atol=1e-7)
+            assert torch.allclose(torch.from_numpy(got), w, rtol=1e-6, atol=1e-7)
 

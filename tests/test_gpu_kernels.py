@@ -246,3 +246,34 @@ def test_relu_bit_masks_producer_and_consumer(H, W, monkeypatch):
     E.conv_tangent(T, 0, *st, w2, 9, y1, *st, B, C, C, H, W, nc, fmode=E.F_RELU, f=act, f_np=C * HW, f_ci=HW, f_px=1, x_sl=sl, y_sl=sl)
     E.conv_tangent(T, 0, *st, w2, 9, y2, *st, B, C, C, H, W, nc, fmode=E.F_RELU_BITS, f=m.data, f_np=m.np_bytes, x_sl=sl, y_sl=sl)
     assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("layout,with_g", [("panel", True), ("fmajor", False), ("panel", False)])
+def test_acl_cross_terms_match_autograd(layout, with_g):
+    """Primal cotangents of the coupling layer's tangent update  out = e^{-s} (v - z gs sd) - gt td  (column reductions)."""
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(17)
+    B, N, NY, n_mod, nc, S = 4, 30, 24, 11, 32, 20
+    zi = torch.randperm(N, generator=gen)[:n_mod].int()
+    ti = torch.randperm(NY // 2, generator=gen)[:n_mod].int()
+    si = ti + NY // 2
+    maps = {"zi": zi.cuda(), "si": si.cuda(), "ti": ti.cuda(), "n": n_mod}
+    z, y = torch.randn(B, N, generator=gen), 0.5 * torch.randn(B, NY, generator=gen)
+    g = torch.rand(B, NY, generator=gen) + 0.2 if with_g else None
+    t_in, yt, c = (torch.randn(B, n, S, generator=gen) for n in (N, NY, N))
+    zd, yd = z.double().requires_grad_(True), y.double().requires_grad_(True)
+    gd = g.double().requires_grad_(True) if with_g else torch.ones(B, NY, dtype=torch.float64)
+    zl, sl, tl = zi.long(), si.long(), ti.long()
+    out = torch.exp(-yd[:, sl]).unsqueeze(-1) * (t_in.double()[:, zl] - (zd[:, zl] * gd[:, sl]).unsqueeze(-1) * yt.double()[:, sl]) \
+        - gd[:, tl].unsqueeze(-1) * yt.double()[:, tl]
+    (out * c.double()[:, zl]).sum().backward()
+    T = E.Tangent.from_dense(t_in.cuda(), nc, layout)
+    V = E.modified_rows(T, maps)
+    assert rel(V.to_dense(S), t_in[:, zl]) == 0.0
+    dz, dy = torch.zeros(B, N).cuda(), torch.zeros(B, NY).cuda()
+    dg = torch.zeros(B, NY).cuda() if with_g else None
+    E.acl_cross_terms(E.Tangent.from_dense(c.cuda(), nc, layout), V, E.Tangent.from_dense(yt.cuda(), nc, layout), z.cuda(), y.cuda(),
+                      None if g is None else g.cuda(), maps, dz, dy, dg)
+    assert rel(dz, zd.grad) < 1e-5 and rel(dy, yd.grad) < 1e-5
+    if with_g:
+        assert rel(dg, gd.grad) < 1e-5
