@@ -43,7 +43,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(cmf_conv_tangent_arg
   const int HW = a.H * a.W, nsl = a.nc / 16;
   const long long xsl = a.x_sl ? a.x_sl : 16, ysl = a.y_sl ? a.y_sl : 16;
   const int fgrp = a.f_group > 1 ? a.f_group : 1;
-  const bool has_f = a.f != nullptr && a.fmode != CMF_F_NONE;
+  const bool self = a.fmode == CMF_F_SELF_RELU;                    // x's own relu, elementwise (primal data in the column slots)
+  const bool has_f = a.f != nullptr && a.fmode != CMF_F_NONE && !self;
 
   const int co = co0 + c * 16 + r;
   const long long gy_lane = (long long)(co < a.cout ? co : a.cout - 1) * a.y_co + 4 * q;   // rows >= cout: dropped by the reduction
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(cmf_conv_tangent_arg
       const float mj = has_f ? factor_of(m[j], a.fmode) : 1.f;
       f32x4 w;                                                     // a select, not a 0-multiplier: 0 * inf would be NaN
 #pragma unroll
-      for (int k = 0; k < 4; ++k) w[k] = ok[j] ? v[j][k] * mj : 0.f;
+      for (int k = 0; k < 4; ++k) w[k] = ok[j] ? (self ? fmaxf(v[j][k], 0.f) : v[j][k] * mj) : 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[k], w[k], acc[j], 0, 0, 0);
     }
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_kernel(cmf_conv_tangent_
   const int W = a.W, H = a.H, nsl = a.nc / 16;
   const long long xsl = a.x_sl ? a.x_sl : 16, ysl = a.y_sl ? a.y_sl : 16;
   const int fgrp = a.f_group > 1 ? a.f_group : 1;
-  const bool has_f = a.f != nullptr && a.fmode != CMF_F_NONE;
+  const bool self = a.fmode == CMF_F_SELF_RELU;
+  const bool has_f = a.f != nullptr && a.fmode != CMF_F_NONE && !self;
   // factor = c0 + c1 [f > 0] + c2 f + c3 f^2  (NONE: 1, RELU: [f > 0], TANH: 1 - f^2, RAW: f) -- branch-free
   const float fc0 = (!has_f || a.fmode == CMF_F_TANH) ? 1.f : 0.f, fc1 = (has_f && a.fmode == CMF_F_RELU) ? 1.f : 0.f;
   const float fc2 = (has_f && a.fmode == CMF_F_RAW) ? 1.f : 0.f, fc3 = (has_f && a.fmode == CMF_F_TANH) ? -1.f : 0.f;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_kernel(cmf_conv_tangent_
         const float f = cs.f[il][dy];
         const float m = fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cs.v[il][dy][k] = ok ? cs.v[il][dy][k] * m : 0.f;
+        for (int k = 0; k < 4; ++k) cs.v[il][dy][k] = ok ? (self ? fmaxf(cs.v[il][dy][k], 0.f) : cs.v[il][dy][k] * m) : 0.f;
       }
 #pragma unroll
     for (int k = 0; k < 4; ++k) g[k] = gbit ? g[k] : 0.f;
@@ -305,8 +307,8 @@ extern "C" int cmf_conv_tangent_wgrad(const cmf_conv_tangent_args* a, const floa
   if (!a || !a->x || !gy || !dw || !ws) return CMF_EINVAL;
   if (a->taps != 9 && a->taps != 1) return CMF_EINVAL;
   if (a->np <= 0 || a->cin <= 0 || a->cout <= 0 || a->H <= 0 || a->W <= 0 || a->nc <= 0 || a->nc % 16) return CMF_EINVAL;
-  if (a->fmode == CMF_F_RELU_BITS || a->fmode == CMF_F_SELF_RELU) return CMF_EINVAL;   // fp32 factor tensors only
-  if (a->fmode != CMF_F_NONE && !a->f) return CMF_EINVAL;
+  if (a->fmode == CMF_F_RELU_BITS) return CMF_EINVAL;                                    // fp32 factor tensors only
+  if (a->fmode != CMF_F_NONE && a->fmode != CMF_F_SELF_RELU && !a->f) return CMF_EINVAL;
   if (ws_bytes < cmf_conv_tangent_wgrad_ws(a)) return CMF_EINVAL;
   // 16-byte column quads on both operands
   if (((uintptr_t)a->x | (uintptr_t)gy) % 16 || (a->x_np | a->x_ci | a->x_px | a->x_sl | a->y_np | a->y_co | a->y_px | a->y_sl) % 4)

@@ -354,6 +354,24 @@ def acl_cross_terms(Ct, V, YT, z, y, g, maps, dz, dy, dg):
                "cmf_acl_cross_terms")
 
 
+def stanh_backward(dy, dg, y, g, sw, sb, dsw=None, dsb=None):
+    """ScaledTanh output stage backward: returns du for y = sw tanh(u) + sb, g = sw (1 - tanh^2) given the cotangents of y and g
+    (``dg`` may be None); accumulates the parameter gradients into ``dsw`` / ``dsb`` (C floats each) when given."""
+    B, Cc = y.shape[0], y.shape[1]
+    HW = y[0, 0].numel()
+    du = torch.empty_like(y)
+    _lib.check(_lib.load().cmf_stanh_backward(_p(dy.contiguous()), _p(None if dg is None else dg.contiguous()), _p(y), _p(g),
+                                              _p(sw.detach().reshape(-1).contiguous()), _p(sb.detach().reshape(-1).contiguous()),
+                                              _p(du), _p(dsw), _p(dsb), B, Cc, HW, _stream()), "cmf_stanh_backward")
+    return du
+
+
+def channel_sum(t, t_np, t_c, t_px, np_, Cc, npx, nc, out, t_sl=16):
+    """out[c] += sum of a tangent-layout tensor over samples, pixels and columns (bias gradients)."""
+    _lib.check(_lib.load().cmf_channel_sum(_p(t), int(t_np), int(t_c), int(t_px), int(t_sl), int(np_), int(Cc), int(npx), int(nc),
+                                           _p(out), _stream()), "cmf_channel_sum")
+
+
 class GramResult:
     __slots__ = ("jtj", "logdet", "l1_off", "l1_diag", "info", "fail", "attempts")
 

@@ -107,7 +107,7 @@ int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* a, void* stream);
 /* Weight gradient of the tangent convolution (training; the reference gets it from autograd through
  * get_conv2d_jvp / get_linear_jvp, jvp_layers.py:49-64, under loss.backward(), trainer.py:213):
  *     dw[co][ci][tap] += sum_{np, px, col} gy(np, co, px, col) * F(np, ci, px+tap) * x(np, ci, px+tap, col)
- * `a` describes the FORWARD launch: x, f, fmode (NONE / RELU / TANH / RAW), f_group, np, cin, cout, H, W, nc, taps and the
+ * `a` describes the FORWARD launch: x, f, fmode (NONE / RELU / TANH / RAW, or SELF_RELU: x's own relu, elementwise), f_group, np, cin, cout, H, W, nc, taps and the
  * strides are read from it; gy is the cotangent of y and is addressed like y (y_np, y_co, y_px, y_sl); a->w, y, r, bias,
  * fo and mask_out are ignored.  dw: [cout][cin][taps] fp32 (the nn.Conv2d / nn.Linear weight layout), accumulated into.
  * ws: caller-owned workspace of cmf_conv_tangent_wgrad_ws(a) bytes (partial sums, reduced in a fixed order).         */
@@ -239,6 +239,18 @@ int cmf_elbo_combine(const float* low, const float* logdet, const float* rec, co
  * The reference's solver (gpytorch linear_cg @ fc2053b) is un-vendored: CG iterates are parity-unpinned. */
 int cmf_hutch_cg(const float* jtj, const float* eps, int d, int S, int B, int max_iter, int min_iter, float tol,
                  float* u, float* w, float* val, int* iters, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Non-convolution pieces of the coupler networks' primal backward.
+ * ScaledTanh2dModule (networks.py:96-113), y = sw tanh(u) + sb, g = sw (1 - tanh(u)^2); y, g, dy, dg, du: (B, C, HW):
+ *   du = dy g - 2 dg tanh(u) g;   dsw[c] += sum dy tanh(u) + dg (1 - tanh(u)^2);   dsb[c] += sum dy
+ * dg (cotangent of g, from cmf_acl_cross_terms) may be NULL; dsw / dsb may be NULL.                                */
+int cmf_stanh_backward(const float* dy, const float* dg, const float* y, const float* g, const float* sw,
+                       const float* sb, float* du, float* dsw, float* dsb, int B, int C, int HW, void* stream);
+/* out[c] += sum_{n, px, col} t(n, c, px, col) over a tangent-layout tensor (element at n*t_np + c*t_c + px*t_px +
+ * (col/16)*t_sl + col%16, t_sl = 0 meaning 16): the bias gradient of nn.Conv2d / nn.Linear.                        */
+int cmf_channel_sum(const float* t, long long t_np, long long t_c, long long t_px, long long t_sl, int np, int C,
+                    int npx, int nc, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimiser step over one flat fp32 buffer: replaces the per-parameter loop of

@@ -67,7 +67,7 @@ def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, monke
     (64, 64, 14, 14, 9, 32), (64, 64, 6, 7, 9, 64), (2, 64, 14, 14, 9, 16), (1, 64, 8, 8, 9, 16), (64, 4, 14, 14, 1, 32),
     (128, 64, 4, 14, 9, 16), (96, 130, 3, 5, 9, 16), (17, 40, 5, 7, 9, 32), (130, 70, 1, 37, 1, 16), (10, 128, 1, 50, 1, 16),
 ])
-@pytest.mark.parametrize("fmode", ["none", "relu", "tanh"])
+@pytest.mark.parametrize("fmode", ["none", "relu", "tanh", "self"])
 @pytest.mark.parametrize("layout", ["panel", "slice"])
 def test_conv_tangent_weight_gradient(cin, cout, H, W, taps, nc, fmode, layout):
     """dW of  <gy, conv(F x)>  against torch.autograd in float64; accumulates into an existing gradient."""
@@ -79,10 +79,12 @@ def test_conv_tangent_weight_gradient(cin, cout, H, W, taps, nc, fmode, layout):
     x = torch.randn(B, cin, H, W, nc, generator=gen)
     gy = torch.randn(B, cout, H, W, nc, generator=gen)
     prim = torch.randn(B, cin, H, W, generator=gen)
-    fac = {"none": torch.ones_like(prim), "relu": (prim > 0).float(), "tanh": 1 - torch.tanh(prim) ** 2}[fmode]
-    src = {"none": None, "relu": prim, "tanh": torch.tanh(prim)}[fmode]
+    fac = {"none": torch.ones_like(prim), "relu": (prim > 0).float(), "tanh": 1 - torch.tanh(prim) ** 2,
+           "self": torch.ones_like(prim)}[fmode]
+    src = {"none": None, "relu": prim, "tanh": torch.tanh(prim), "self": None}[fmode]
     w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
-    xin = (x * fac.unsqueeze(-1)).permute(0, 4, 1, 2, 3).reshape(B * nc, cin, H, W).double()
+    xe = torch.relu(x) if fmode == "self" else x                   # SELF_RELU: the input's own relu (primal data in the column slots)
+    xin = (xe * fac.unsqueeze(-1)).permute(0, 4, 1, 2, 3).reshape(B * nc, cin, H, W).double()
     y = F.conv2d(xin, w, padding=1 if taps == 9 else 0)
     (y * gy.permute(0, 4, 1, 2, 3).reshape(B * nc, cout, H, W).double()).sum().backward()
     if layout == "panel":
@@ -97,7 +99,7 @@ def test_conv_tangent_weight_gradient(cin, cout, H, W, taps, nc, fmode, layout):
     prev = torch.randn(cout, cin, k, k, generator=gen)
     dw = prev.clone().cuda()
     E.conv_tangent_wgrad(to_dev(x), 0, *st(cin), to_dev(gy), 0, *st(cout), dw, taps, B, cin, cout, H, W, nc,
-                         fmode={"none": E.F_NONE, "relu": E.F_RELU, "tanh": E.F_TANH}[fmode],
+                         fmode={"none": E.F_NONE, "relu": E.F_RELU, "tanh": E.F_TANH, "self": E.F_SELF_RELU}[fmode],
                          f=None if src is None else src.cuda(), f_np=cin * HW, f_ci=HW, f_px=1, x_sl=sl(cin), y_sl=sl(cout))
     assert rel(dw.cpu() - prev, w.grad) < 2e-5
 
@@ -277,3 +279,37 @@ def test_acl_cross_terms_match_autograd(layout, with_g):
     assert rel(dz, zd.grad) < 1e-5 and rel(dy, yd.grad) < 1e-5
     if with_g:
         assert rel(dg, gd.grad) < 1e-5
+
+
+def test_scaled_tanh_backward_matches_autograd():
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(23)
+    B, Cc, H, W = 5, 4, 7, 6
+    u = torch.randn(B, Cc, H, W, generator=gen).double().requires_grad_(True)
+    sw = (torch.randn(Cc, 1, 1, generator=gen) + 1.5).double().requires_grad_(True)
+    sb = torch.randn(Cc, 1, 1, generator=gen).double().requires_grad_(True)
+    dy, dg = torch.randn(B, Cc, H, W, generator=gen), torch.randn(B, Cc, H, W, generator=gen)
+    t = torch.tanh(u)
+    y, g = sw * t + sb, sw * (1 - t * t)
+    for use_dg in (True, False):
+        gu, gw, gb = torch.autograd.grad((y * dy.double()).sum() + ((g * dg.double()).sum() if use_dg else 0), [u, sw, sb],
+                                         retain_graph=True)
+        dsw, dsb = torch.ones(Cc).cuda(), torch.ones(Cc).cuda()     # accumulated into
+        du = E.stanh_backward(dy.cuda(), dg.cuda() if use_dg else None, y.detach().float().cuda(), g.detach().float().cuda(),
+                              sw.detach().float().cuda(), sb.detach().float().cuda(), dsw, dsb)
+        assert rel(du, gu) < 1e-5 and rel(dsw - 1, gw.reshape(-1)) < 1e-5 and rel(dsb - 1, gb.reshape(-1)) < 1e-5
+
+
+@pytest.mark.parametrize("layout", ["panel", "slice"])
+def test_channel_sum(layout):
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(29)
+    B, Cc, HW, nc = 3, 40, 35, 32
+    t = torch.randn(B, Cc, HW, nc, generator=gen)
+    out = torch.full((Cc,), 2.0).cuda()
+    if layout == "panel":
+        E.channel_sum(t.cuda(), Cc * HW * nc, HW * nc, nc, B, Cc, HW, nc, out)
+    else:
+        dev = t.reshape(B, Cc, HW, nc // 16, 16).permute(0, 2, 3, 1, 4).contiguous().cuda()
+        E.channel_sum(dev, Cc * HW * nc, 16, Cc * nc, B, Cc, HW, nc, out, t_sl=Cc * 16)
+    assert rel(out - 2, t.double().sum((0, 2, 3))) < 1e-5
