@@ -277,10 +277,17 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
 #pragma unroll
       for (int c = 0; c < COT; ++c) {
         if (is_full || (co0 + c * 16) < a.cout) {
-          float mo = 1.f;                                  // output-side factor (reverse sweep): NONE / RELU / TANH / RAW
-          if (a.fo) {
+          f32x4 mo = {1.f, 1.f, 1.f, 1.f};                 // output-side factor (reverse sweep): NONE / RELU / TANH / RAW
+          if (a.fo && a.fomode == CMF_F_SELF_RELU) {
+            // per-COLUMN relu' (primal backward, 16 samples in the column slots): fo is laid out like y
+            const f32x4 fv = *reinterpret_cast<const f32x4*>(a.fo + (long long)np * a.fo_np + (long long)slice * (a.y_sl ? a.y_sl : 16) +
+                                                             kq * 4 + (long long)(co0 + c * 16) * a.fo_co + (long long)gpix * a.fo_px);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mo[r] = fv[r] > 0.f ? 1.f : 0.f;
+          } else if (a.fo) {
             const float fv = a.fo[(long long)np * a.fo_np + (long long)(co0 + c * 16) * a.fo_co + (long long)gpix * a.fo_px];
-            mo = a.fomode == CMF_F_RELU ? (fv > 0.f ? 1.f : 0.f) : a.fomode == CMF_F_TANH ? 1.f - fv * fv : fv;
+            const float m1 = a.fomode == CMF_F_RELU ? (fv > 0.f ? 1.f : 0.f) : a.fomode == CMF_F_TANH ? 1.f - fv * fv : fv;
+            mo = f32x4{m1, m1, m1, m1};
           }
           f32x4 v = acc[p][c] * mo + bias[c];
           if (has_res) v += *reinterpret_cast<const f32x4*>(rp + (c * 16) * r_co);
@@ -369,7 +376,8 @@ extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
   if ((a.x_np | a.x_ci | a.x_px | a.x_sl | a.y_sl | a.r_sl) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
   if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;            // 16-byte stores
   if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;    // 16-byte residual loads
-  if (a.fo && (a.fomode < CMF_F_RELU || a.fomode > CMF_F_RAW)) return CMF_EINVAL;
+  if (a.fo && (a.fomode < CMF_F_RELU || a.fomode > CMF_F_SELF_RELU)) return CMF_EINVAL;
+  if (a.fo && a.fomode == CMF_F_SELF_RELU && ((a.fo_np | a.fo_co | a.fo_px) % 4 || (uintptr_t)a.fo % 16)) return CMF_EINVAL;
   if (a.mask_out && (a.cout % 16 || a.mask_np < (long long)a.H * a.W * (a.cout / 8))) return CMF_EINVAL;
   const long long HW = (long long)a.H * a.W;
   // per-sample offsets are held in 32-bit registers

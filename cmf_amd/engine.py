@@ -764,3 +764,59 @@ def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None):
             conv_tangent(c_t, 0, 0, B * nc, nc, lin.weight, 1, out.data, 0, B * nc, nc, 1, cin, lin.in_features, 1, B, nc,
                          fo=acts[i - 1], fo_np=0, fo_co=1, fo_px=lin.in_features, fomode=F_TANH, **f32)
             c_t, cin = out.data, lin.in_features
+
+
+def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
+    """Primal backward of a ResNet coupler network (training): given the cotangents ``dy`` of its output
+    ``y = sw tanh(u) + sb`` and ``dg`` of the tangent multiplier ``g`` (from ``acl_cross_terms``; may be None), accumulates
+    the gradients of every weight, bias and of the ScaledTanh parameters into ``grads`` and the cotangent of the rows of
+    ``z`` the network read into ``dz``.  ``acts`` = the per-sample float activations ``net_primal(need_acts=True)`` returned.
+    Runs on the tangent-conv kernels with 16 samples in the column slots: transposed packs with the per-column output factor
+    (``CMF_F_SELF_RELU`` as fomode), ``cmf_conv_tangent_wgrad`` with the input's own relu, ``cmf_channel_sum`` for biases."""
+    assert net.kind == "resnet", "MLP couplers: the tanh layers add second-order cross terms that are not built yet"
+    geo, B, dev = view.geom, z.shape[0], z.device
+    conv0, blocks, convf = _resnet_parts(net)
+    hid, cout, H, W, HW = conv0.out_channels, convf.out_channels, geo.H, geo.W, geo.HW
+    Bp = (B + 15) // 16 * 16
+    G = Bp // 16
+
+    def grp(t):                                            # (B, C, H, W) -> flat grouped (G, C, HW, 16), zero-padded samples
+        t = t.reshape(B, -1)
+        if Bp != B:
+            t = torch.cat([t, torch.zeros(Bp - B, t.shape[1], dtype=t.dtype, device=dev)])
+        return primal_regroup(t.contiguous(), True)
+
+    pn = lambda c: (c * HW * 16, HW * 16, 16)
+    new = lambda c: torch.empty(G * c * HW * 16, dtype=torch.float32, device=dev)
+    tr = dict(transpose=True, precision="f32")
+    self_fo = lambda t: dict(fo=t, fo_np=hid * HW * 16, fo_co=HW * 16, fo_px=16, fomode=F_SELF_RELU)
+    du = stanh_backward(dy, dg, y, g, net.weights, net.bias, _grad_of(grads, net.weights).view(-1), _grad_of(grads, net.bias).view(-1))
+    du_g, a_g = grp(du), grp(acts[-1])
+    # u = convf(relu(a_K)) + bf
+    conv_tangent_wgrad(a_g, 0, *pn(hid), du_g, 0, *pn(cout), _grad_of(grads, convf.weight), 1, G, hid, cout, H, W, 16, fmode=F_SELF_RELU)
+    channel_sum(du_g, *pn(cout), G, cout, HW, 16, _grad_of(grads, convf.bias))
+    da = new(hid)
+    conv_tangent(du_g, 0, *pn(cout), convf.weight, 1, da, *pn(hid), G, cout, hid, H, W, 16, **self_fo(a_g), **tr)
+    for k in reversed(range(len(blocks))):
+        blk = blocks[k]
+        a_in, c1 = grp(acts[2 * k]), grp(acts[2 * k + 1])
+        # a' = a + conv2(relu(c1)) + b2,  c1 = conv1(relu(a)) + b1
+        conv_tangent_wgrad(c1, 0, *pn(hid), da, 0, *pn(hid), _grad_of(grads, blk.conv2.weight), 9, G, hid, hid, H, W, 16, fmode=F_SELF_RELU)
+        channel_sum(da, *pn(hid), G, hid, HW, 16, _grad_of(grads, blk.conv2.bias))
+        dc1 = new(hid)
+        conv_tangent(da, 0, *pn(hid), blk.conv2.weight, 9, dc1, *pn(hid), G, hid, hid, H, W, 16, **self_fo(c1), **tr)
+        conv_tangent_wgrad(a_in, 0, *pn(hid), dc1, 0, *pn(hid), _grad_of(grads, blk.conv1.weight), 9, G, hid, hid, H, W, 16, fmode=F_SELF_RELU)
+        channel_sum(dc1, *pn(hid), G, hid, HW, 16, _grad_of(grads, blk.conv1.bias))
+        da2 = new(hid)
+        conv_tangent(dc1, 0, *pn(hid), blk.conv1.weight, 9, da2, *pn(hid), G, hid, hid, H, W, 16, res_t=da, **self_fo(a_in), **tr)
+        da = da2
+    # a_0 = conv0(mask . z[view])   (no bias)
+    cin, m = view.cin, view.mask
+    rows = z.reshape(B, geo.C, HW)[:, view.chan_off::view.chan_step][:, :cin]
+    x0 = grp(rows)
+    fm = dict(fmode=F_RAW, f=m, f_np=0, f_ci=HW, f_px=1) if m is not None else {}
+    conv_tangent_wgrad(x0, 0, *pn(cin), da, 0, *pn(hid), _grad_of(grads, conv0.weight), 9, G, cin, hid, H, W, 16, **fm)
+    dx0 = new(cin)
+    fo = dict(fo=m, fo_np=0, fo_co=HW, fo_px=1, fomode=F_RAW) if m is not None else {}
+    conv_tangent(da, 0, *pn(hid), conv0.weight, 9, dx0, *pn(cin), G, hid, cin, H, W, 16, **fo, **tr)
+    dz.reshape(B, geo.C, HW)[:, view.chan_off::view.chan_step][:, :cin] += primal_regroup(dx0.view(G, -1), False).view(Bp, cin, HW)[:B]

@@ -85,7 +85,9 @@ typedef struct {
   const float* fo; long long fo_np, fo_co, fo_px; int fomode;
                                                 /* OUTPUT-side factor (cmf_conv_tangent only; the split kernel rejects
                                                    it): y = Fo(np, co, px) * conv(F * x) + bias + r, Fo derived from fo
-                                                   by fomode like F from f (NONE / RELU / TANH / RAW).  This is what the
+                                                   by fomode like F from f (NONE / RELU / TANH / RAW; SELF_RELU: fo is laid
+                                                   out like y, columns included, and Fo = [fo > 0] per column -- primal
+                                                   backward with 16 samples in the column slots).  This is what the
                                                    reverse (cotangent) sweep needs: the adjoint of "mask, then conv" is
                                                    "transposed conv, then mask" (weights from cmf_pack_weight(transpose=1)) */
   void* mask_out; long long mask_np;            /* cmf_conv_tangent only, cout % 16 == 0: also write the sign bits of the

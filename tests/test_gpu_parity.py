@@ -471,3 +471,49 @@ def test_coupler_net_weight_gradients_match_autograd(name):
         assert len(grads) == len(mods)
         for m, gw in zip(mods, want):
             assert rel(grads[m.weight], gw) < 1e-4, (name, type(m).__name__, tuple(m.weight.shape))
+
+
+@pytest.mark.parametrize("name,B", [("mini_mnist", 5), ("mini_cifar", 16)])
+def test_resnet_coupler_primal_backward_matches_autograd(name, B):
+    """f1 building block: primal backward of a ResNet coupler network (ScaledTanh stage, transposed convs with per-column relu',
+    weight / bias gradients, input cotangent) on the tangent-conv kernels with 16 samples in the column slots, against
+    torch.autograd through a float64 restatement; first (checkerboard mask) and last (channel split) coupling layer."""
+    import torch.nn.functional as F
+    from cmf_amd import engine as E
+    from cmf_amd.bijections import AffineCouplingBijection
+    g_, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    layers = [m for m in head.program.layers if isinstance(m, AffineCouplingBijection)]
+    gen = torch.Generator().manual_seed(6)
+    for bij in (layers[0], layers[-1]):
+        geo, net = bij.geom, bij.net
+        view = bij.view("cuda")
+        conv0, blocks, convf = E._resnet_parts(net)
+        with torch.no_grad():
+            z = torch.randn(B, *geo.shape, generator=gen).cuda()
+            y, g, acts = E.net_primal(net, z, view, need_acts=True)
+            dy, dg = torch.randn(y.shape, generator=gen), torch.randn(y.shape, generator=gen)
+            grads, dz = {}, torch.zeros_like(z)
+            E.net_primal_backward(net, z, view, acts, y, g, dy.cuda(), dg.cuda(), grads, dz)
+        params = [conv0.weight] + [p for b in blocks for p in (b.conv1.weight, b.conv1.bias, b.conv2.weight, b.conv2.bias)] + \
+                 [convf.weight, convf.bias, net.weights, net.bias]
+        p64 = [p.detach().cpu().double().requires_grad_(True) for p in params]
+        it = iter(p64)
+        zd = z.cpu().double().requires_grad_(True)
+        chans = [view.chan_off + i * view.chan_step for i in range(view.cin)]
+        x0 = zd[:, chans]
+        if view.mask is not None:
+            x0 = x0 * view.mask.detach().cpu().double().reshape(1, view.cin, geo.H, geo.W)
+        a = F.conv2d(x0, next(it), padding=1)
+        for _ in blocks:
+            c1 = F.conv2d(torch.relu(a), next(it), next(it), padding=1)
+            a = a + F.conv2d(torch.relu(c1), next(it), next(it), padding=1)
+        u = F.conv2d(torch.relu(a), next(it), next(it))
+        sw, sb = next(it), next(it)
+        t = torch.tanh(u)
+        yy, gg = sw * t + sb, sw * (1 - t * t)
+        assert rel(y, yy) < 1e-5 and rel(g, gg) < 1e-4
+        want = torch.autograd.grad((yy * dy.double()).sum() + (gg * dg.double()).sum(), p64 + [zd])
+        assert rel(dz, want[-1]) < 1e-4
+        for p, w in zip(params, want[:-1]):
+            assert rel(grads[p], w.reshape(p.shape)) < 1e-4, (name, tuple(p.shape))
