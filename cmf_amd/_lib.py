@@ -55,6 +55,7 @@ SIGNATURES = {
     "cmf_acl_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "cmf_acl_tangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _fp]),
     "cmf_acl_cotangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _fp]),
+    "cmf_acl_primal_backward": (_i, [_fp, _ll, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "cmf_acl_cross_terms": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i,
                             _fp, _fp, _fp, _fp]),
     "cmf_gather_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _i, _i, _fp]),

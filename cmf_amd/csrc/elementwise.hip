@@ -106,6 +106,33 @@ __global__ void acl_cotangent_kernel(float* __restrict__ c, long long c_b, long 
   *cp = es * v;
 }
 
+// acl primal backward (training), flat over (b, e), in place on the primal cotangent dx (full tensor; pass-through elements
+// keep their value):
+//   decode  x_mod = z_mod e^{-s} - t :  dz_mod = dx e^{-s};  dy[s] -= dx z_mod e^{-s};  dy[t] -= dx          (z = tensor BEFORE)
+//   encode  z_mod = (x_mod + t) e^{s}:  dx_mod = dz e^{s};   dy[t] += dz e^{s};  dy[s] += dz (x_mod + t) e^{s} + dlj[b]
+__global__ void acl_primal_backward_kernel(float* __restrict__ dx, long long dx_b, const float* __restrict__ z, long long z_b,
+                                           const float* __restrict__ y, long long y_b, float* __restrict__ dy,
+                                           const int* __restrict__ zi, const int* __restrict__ si, const int* __restrict__ ti,
+                                           int n_mod, long long total, int decode, const float* __restrict__ dlj) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i % n_mod);
+  const long long b = i / n_mod;
+  const int rs = si[e], rt = ti[e], rz = zi[e];
+  const float s = y[b * y_b + rs], zo = z[b * z_b + rz], d = dx[b * dx_b + rz];
+  if (decode) {
+    const float es = expf(-s);
+    dx[b * dx_b + rz] = d * es;
+    dy[b * y_b + rs] -= d * zo * es;
+    dy[b * y_b + rt] -= d;
+  } else {
+    const float es = expf(s), t = y[b * y_b + rt];
+    dx[b * dx_b + rz] = d * es;
+    dy[b * y_b + rt] += d * es;
+    dy[b * y_b + rs] += d * (zo + t) * es + (dlj ? dlj[b] : 0.f);
+  }
+}
+
 // acl cross terms (training): the tangent update  out = es (v - zo gs sd) - gt td  also depends on PRIMAL quantities;
 // their cotangents are column reductions of c . d(out)/d(.) -- one wavefront per (sample, modified element):
 //   d s  = -sum_col c es (v - zo gs sd)     d zo = -sum_col c es gs sd
@@ -360,6 +387,17 @@ int cmf_acl_cotangent(float* c, long long c_b, long long c_r, float* yc, long lo
   const long long total = (long long)B * n_mod * (nc / 4);
   hipLaunchKernelGGL(acl_cotangent_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, c, c_b, c_r, yc, yc_b,
                      yc_r, nc / 4, z, z_b, y, y_b, g, zi, si, ti, n_mod, total);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+int cmf_acl_primal_backward(float* dx, long long dx_b, const float* z, long long z_b, const float* y, long long y_b, float* dy,
+                            const int* zi, const int* si, const int* ti, int n_mod, int B, int decode, const float* dlj,
+                            void* stream) {
+  if (!dx || !z || !y || !dy || !zi || !si || !ti || n_mod <= 0 || B <= 0) return CMF_EINVAL;
+  const long long total = (long long)B * n_mod;
+  hipLaunchKernelGGL(acl_primal_backward_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, dx, dx_b, z, z_b, y, y_b,
+                     dy, zi, si, ti, n_mod, total, decode, dlj);
   CMF_LAUNCH_CHECK();
   return 0;
 }

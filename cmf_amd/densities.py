@@ -400,6 +400,46 @@ class FlowProgram:
         out = E.gather_tangent(Ct, self.tail.gather_index(dev), self.d)
         return z, out.to_dense(S).contiguous()
 
+    # -- training: decode with saved state, and its backward -------------------------------
+    def decode_train(self, z_low):
+        """``decode(z_low, tangents=True)`` keeping every coupling layer's context; returns (x_hat, T, ctx)."""
+        B, dev = z_low.shape[0], z_low.device
+        N = int(np.prod(self.tail.x_shape))
+        scatter = self.tail.scatter_index(dev)
+        z = E.gather_primal(z_low.contiguous(), scatter, N).view(B, *self.tail.x_shape)
+        T = E.seed_tangent(B, N, E.ceil16(self.d), self.layout, scatter, self.d, dev)
+        ctx = []
+        for m in reversed(self.layers):
+            if isinstance(m, AffineCouplingBijection):
+                ctx.append(m.decode_train_(z, T))
+            elif isinstance(m, SplitDensity):
+                n = z[0].numel()
+                idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),
+                                 torch.full((n,), -1, dtype=torch.int32, device=dev)))
+                z = E.gather_primal(z, idx, 2 * n).view(B, 2 * z.shape[1], *z.shape[2:])
+                T = E.gather_tangent(T, idx, 2 * n)
+                ctx.append(n)
+            else:
+                z, T = m.decode(z, T)
+                ctx.append(None)
+        return z, T, ctx
+
+    def decode_backward(self, ctx, Ct, dx, grads):
+        """Backward of ``decode_train``: ``Ct`` = cotangent of the Jacobian stack at the head (e.g. ``engine.gram_backward``),
+        ``dx`` = cotangent of x_hat.  Accumulates parameter gradients into ``grads`` and returns the cotangent of z_low (B, d)."""
+        B, dev = dx.shape[0], dx.device
+        dx = dx.detach().clone().contiguous()
+        for m, c in zip(self.layers, reversed(ctx)):
+            if isinstance(m, AffineCouplingBijection):
+                m.decode_backward_(Ct, dx, c, grads)
+            elif isinstance(m, SplitDensity):                      # adjoint of the zero-padding: keep the first half
+                Ct = E.gather_tangent(Ct, torch.arange(c, dtype=torch.int32, device=dev), c)
+                dx = dx.reshape(B, -1)[:, :c].reshape(B, dx.shape[1] // 2, *dx.shape[2:]).contiguous()
+            else:
+                Ct = m.decode_vjp(Ct)
+                dx = m.encode(dx)                                  # x[r] = z[z2x[r]]  ->  dz = dx[x2z]
+        return E.gather_primal(dx.reshape(B, -1), self.tail.gather_index(dev), self.d)
+
     # -- latent noise -> z_low (sampling) ----------------------------------------------------------
     def prior_inverse(self, u):
         z = u.detach().clone().contiguous()
@@ -633,6 +673,29 @@ class NonSquareHeadDensity(Density):
         """Dense J (B, D, d) -- the tensor the reference stacks at non_square.py:307."""
         x_hat, T = self.program.decode(z_low, tangents=True)
         return x_hat, T.to_dense(self.program.d).contiguous()
+
+
+    def head_terms_backward(self, z_low, x, g_logdet=None, g_l1off=None, g_l1diag=None, g_rec=None, grads=None):
+        """Training building block: parameter gradients and the latent cotangent of
+            sum_b  g_logdet[b] logdet(J^T J)_b + g_l1off[b] sum_{i!=j}|G_ij| + g_l1diag[b] sum_i |G_ii| + g_rec[b] ||x_hat_b - x_b||^2
+        at FIXED z_low -- the head terms of non_square.py:64-129 that depend on the decode side (the encode / prior chain that
+        produces z_low is not differentiated here).  ResNet couplers only.  Returns a dict with the forward values, ``dz_low``
+        (B, d) and ``grads`` (parameter -> gradient, accumulated into when passed in)."""
+        E.require_gpu(z_low)
+        grads = {} if grads is None else grads
+        d = self.program.d
+        with torch.no_grad():
+            x_hat, T, ctx = self.program.decode_train(z_low.detach())
+            gr = E.gram_cholesky(T, d)
+            if int(gr.fail[0].item()) != 0:
+                raise RuntimeError("J^T J is not positive definite at the first attempt: the jittered retries are not differentiated")
+            Ct = E.gram_backward(T, gr.jtj, g_logdet, g_l1off, g_l1diag)
+            B = z_low.shape[0]
+            dx = torch.zeros_like(x_hat)
+            if g_rec is not None:
+                dx = 2.0 * g_rec.to(torch.float32).view(B, *([1] * (x_hat.dim() - 1))) * (x_hat - x)
+            dz = self.program.decode_backward(ctx, Ct, dx, grads)
+        return {"x_hat": x_hat, "logdet": gr.logdet, "l1_off": gr.l1_off, "l1_diag": gr.l1_diag, "dz_low": dz, "grads": grads}
 
 
 class ManifoldFlowHeadDensity(NonSquareHeadDensity):

@@ -342,6 +342,16 @@ def modified_rows(T, maps):
     return out
 
 
+def acl_primal_backward(dx, z, y, maps, dy, decode, dlj=None):
+    """Primal backward of the coupling update, in place on ``dx`` (z-shaped); accumulates into ``dy`` (y-shaped).  ``z`` = the
+    tensor the forward update read (decode: before the update; encode: the layer input)."""
+    B = z.shape[0]
+    d2, z2, y2 = dx.view(B, -1), z.view(B, -1), y.view(B, -1)
+    _lib.check(_lib.load().cmf_acl_primal_backward(_p(d2), d2.shape[1], _p(z2), z2.shape[1], _p(y2), y2.shape[1], _p(dy), _p(maps["zi"]),
+                                                   _p(maps["si"]), _p(maps["ti"]), maps["n"], B, int(decode), _p(dlj), _stream()),
+               "cmf_acl_primal_backward")
+
+
 def acl_cross_terms(Ct, V, YT, z, y, g, maps, dz, dy, dg):
     """Primal cotangents of the tangent update (training): column reductions accumulated into ``dz`` (like z), ``dy`` (like y:
     the log-scale entries) and ``dg`` (like g).  ``Ct`` must still hold the cotangent of the UPDATED rows: call this before

@@ -163,6 +163,15 @@ int cmf_acl_primal(float* z, long long z_b, const float* y, long long y_b, const
 int cmf_acl_cotangent(float* c, long long c_b, long long c_r, float* yc, long long yc_b, long long yc_r, int nc,
                       const float* z, long long z_b, const float* y, long long y_b, const float* g, const int* zi,
                       const int* si, const int* ti, int n_mod, int B, void* stream);
+/* Primal backward of the coupling update (training), in place on the primal cotangent dx (z-shaped; pass-through elements keep
+ * their value), accumulating the cotangent of the network output into dy (y-shaped):
+ *   decode != 0 (x_mod = z_mod e^{-s} - t, `z` = the tensor BEFORE the update, acl.py:57-66):
+ *       dx[zi] *= e^{-s};  dy[si] -= dx z_mod e^{-s};  dy[ti] -= dx
+ *   decode == 0 (z_mod = (x_mod + t) e^{s}, `z` = the layer INPUT x, acl.py:43-46):
+ *       dx[zi] *= e^{s};   dy[ti] += dz e^{s};  dy[si] += dz (x_mod + t) e^{s} + dlj[b]   (dlj: cotangent of the log-jacobian, or NULL) */
+int cmf_acl_primal_backward(float* dx, long long dx_b, const float* z, long long z_b, const float* y, long long y_b, float* dy,
+                            const int* zi, const int* si, const int* ti, int n_mod, int B, int decode, const float* dlj,
+                            void* stream);
 /* Cross terms of the coupling update for training (autograd through acl.py:48-66, :113-146 in the reference): the tangent
  * update  out(b, zi[e], :) = es (v - zo gs sd) - gt td  of cmf_acl_tangent also depends on primal values.  Given the
  * cotangent c of `out` (rows zi[e], BEFORE cmf_acl_cotangent rewrites them), the saved input rows v (compact: row e at

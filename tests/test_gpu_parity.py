@@ -517,3 +517,46 @@ def test_resnet_coupler_primal_backward_matches_autograd(name, B):
         assert rel(dz, want[-1]) < 1e-4
         for p, w in zip(params, want[:-1]):
             assert rel(grads[p], w.reshape(p.shape)) < 1e-4, (name, tuple(p.shape))
+
+
+@pytest.mark.parametrize("name", ["mini_mnist", "mini_cifar", "mini_mnist_small"])
+def test_head_terms_parameter_gradients_match_oracle_autograd(name):
+    """f1: d/d theta and d/d z_low of  sum_b a_b logdet(J^T J) + o_b sum_{i!=j}|G_ij| + r_b ||x_hat - x||^2  at fixed z_low --
+    tangent sweep with saved state, Gram backward, reverse sweep with weight gradients, coupling-layer cross terms, primal
+    backward of the coupler networks -- against torch.autograd through the float64 CPU oracle (the reference's own route:
+    loss.backward() through the JVP graphs, trainer.py:213)."""
+    from oracle import cmf_oracle as O
+    g, meta, cfg, dens = build(name)
+    _, schema, x_shape, ops, sd = golden_model(meta, dtype=torch.float64)
+    head = find_head(dens)
+    gen = torch.Generator().manual_seed(41)
+    z_low = g["z_low"][:3].float()
+    B, d = z_low.shape
+    a, o, r = (torch.randn(B, generator=gen) for _ in range(3))
+    xt = torch.randn(B, *head.program.tail.x_shape if False else g["x_hat"].shape[1:], generator=gen)
+    # oracle, float64, autograd
+    keys = [k for k, v in sd.items() if v.is_floating_point() and any(k.endswith(s) for s in (".weight", ".bias", ".weights"))]
+    sd64 = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    pre, hd, flow_ops, base, prior_ops = O.split_ops(ops)
+    zd = z_low.double().requires_grad_(True)
+    jtj, xh, J = O.jtj_batched(sd64, flow_ops, base, zd)
+    logdet, jtj2, attempts = O.cholesky_logdet(jtj)
+    assert attempts == 1
+    loss = (a.double() * logdet.view(-1) + o.double() * O.metric_l1(jtj, False).view(-1)
+            + r.double() * ((xh - xt.double()).flatten(1) ** 2).sum(1)).sum()
+    used = [k for k in keys]
+    want = torch.autograd.grad(loss, [sd64[k] for k in used] + [zd], allow_unused=True)
+    out = head.head_terms_backward(z_low.cuda(), xt.cuda(), g_logdet=a.cuda(), g_l1off=o.cuda(), g_rec=r.cuda())
+    assert rel(out["x_hat"], xh) < 1e-5 and rel(out["logdet"], logdet.view(-1)) < 1e-4
+    assert rel(out["dz_low"], want[-1]) < 2e-4
+    named = dict(dens.named_parameters())
+    checked = 0
+    for k, w in zip(used, want[:-1]):
+        p = named[k]
+        if w is None:                                   # parameters outside the decode path (prior flows)
+            assert p not in out["grads"]
+            continue
+        assert p in out["grads"], k
+        assert rel(out["grads"][p], w.reshape(p.shape)) < 5e-4, k
+        checked += 1
+    assert checked >= 30
