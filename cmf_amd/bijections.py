@@ -191,6 +191,26 @@ class AffineCouplingBijection(Bijection):
         dx += dz_ct
         E.net_primal_backward(self.net, zb, view, acts, y, g, dy, dg, grads, dx)
 
+    def encode_train_(self, z, lj=None):
+        """``encode_`` keeping the layer input, the network output and its activations for ``encode_backward_``."""
+        view = self.view(z.device)
+        xb = z.clone()
+        y, g, acts = E.net_primal(self.net, z, view, need_acts=True)
+        E.acl_primal(z, y, self.maps(z.device), decode=False, lj=lj)
+        return xb, y, g, acts
+
+    def encode_backward_(self, dz, ctx, grads, dlj=None):
+        """Backward of ``encode_train_`` in place on ``dz`` (cotangent of the layer output -> of its input); ``dlj`` (B,) is the
+        cotangent of the layer's log-jacobian where it is used (the low-dimensional prior flows)."""
+        xb, y, g, acts = ctx
+        dev = xb.device
+        dy = torch.zeros_like(y)
+        E.acl_primal_backward(dz, xb, y, self.maps(dev), dy, decode=False, dlj=dlj)
+        if self.net.kind == "resnet":
+            E.net_primal_backward(self.net, xb, self.view(dev), acts, y, g, dy, None, grads, dz)
+        else:
+            E.mlp_primal_backward(self.net, xb, self.view(dev), acts, dy, grads, dz)
+
     # protocol ------------------------------------------------------------------------------------
     def _x_to_z(self, x):
         E.require_gpu(x)

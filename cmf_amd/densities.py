@@ -440,6 +440,59 @@ class FlowProgram:
                 dx = m.encode(dx)                                  # x[r] = z[z2x[r]]  ->  dz = dx[x2z]
         return E.gather_primal(dx.reshape(B, -1), self.tail.gather_index(dev), self.d)
 
+    def encode_train(self, x):
+        """``encode`` keeping every layer's context: returns (z_low, low_dim_elbo, u, ctx, prior_ctx)."""
+        B = x.shape[0]
+        h = x.detach().clone().contiguous()
+        ctx = []
+        for m in self.layers:
+            if isinstance(m, AffineCouplingBijection):
+                ctx.append(m.encode_train_(h))
+            elif isinstance(m, SplitDensity):
+                n = h[0].numel() // 2
+                idx = torch.arange(n, dtype=torch.int32, device=h.device)
+                h = E.gather_primal(h, idx, n).view(B, h.shape[1] // 2, *h.shape[2:])
+                ctx.append(n)
+            else:
+                h = m.encode(h)
+                ctx.append(None)
+        z_low = E.gather_primal(h, self.tail.gather_index(h.device), self.d)
+        u = z_low.clone()
+        lj = torch.zeros(B, dtype=torch.float32, device=x.device)
+        pctx = []
+        for m in self.prior:
+            if isinstance(m, AffineCouplingBijection):
+                pctx.append((m, m.encode_train_(u, lj)))
+            elif isinstance(m, AffineBijection):
+                raise NotImplementedError("training gradients through the 2-D AffineBijection prior are not built")
+        if self.gaussian._nonstandard():
+            raise NotImplementedError("training gradients with a non-standard base Gaussian are not built")
+        self.gaussian.logprob_accumulate(u, lj)
+        return z_low, lj, u, ctx, pctx
+
+    def prior_backward(self, pctx, u, dlow, grads):
+        """Backward of the low-dimensional prior chain: ``dlow`` (B,) = cotangent of low_dim_elbo = log N(u) + sum log-jac;
+        returns the cotangent of z_low (B, d) and accumulates the prior flows' parameter gradients."""
+        du = (-u * dlow.view(-1, 1)).contiguous()
+        for m, c in reversed(pctx):
+            m.encode_backward_(du, c, grads, dlj=dlow)
+        return du
+
+    def encode_backward(self, ctx, dz_low, grads):
+        """Backward of the encode chain above the base: cotangent of z_low -> parameter gradients (and the unused cotangent of x)."""
+        B, dev = dz_low.shape[0], dz_low.device
+        N = int(np.prod(self.tail.x_shape))
+        dh = E.gather_primal(dz_low.contiguous(), self.tail.scatter_index(dev), N).view(B, *self.tail.x_shape)
+        for m, c in zip(reversed(self.layers), reversed(ctx)):
+            if isinstance(m, AffineCouplingBijection):
+                m.encode_backward_(dh, c, grads)
+            elif isinstance(m, SplitDensity):                      # the dropped half gets no gradient
+                idx = torch.cat((torch.arange(c, dtype=torch.int32, device=dev), torch.full((c,), -1, dtype=torch.int32, device=dev)))
+                dh = E.gather_primal(dh, idx, 2 * c).view(B, 2 * dh.shape[1], *dh.shape[2:])
+            else:
+                dh = m.decode(dh, None)[0]                         # z[r] = x[x2z[r]]  ->  dx = dz[z2x]
+        return dh
+
     # -- latent noise -> z_low (sampling) ----------------------------------------------------------
     def prior_inverse(self, u):
         z = u.detach().clone().contiguous()
@@ -696,6 +749,44 @@ class NonSquareHeadDensity(Density):
                 dx = 2.0 * g_rec.to(torch.float32).view(B, *([1] * (x_hat.dim() - 1))) * (x_hat - x)
             dz = self.program.decode_backward(ctx, Ct, dx, grads)
         return {"x_hat": x_hat, "logdet": gr.logdet, "l1_off": gr.l1_off, "l1_diag": gr.l1_diag, "dz_low": dz, "grads": grads}
+
+
+    def loss_and_gradients(self, x, add_reconstruction=True, add_diagonal_metric_reg=False, add_offdiagonal_metric_reg=False,
+                           likelihood_wt=1., metric_wt=1., pre_logjac=None, grads=None):
+        """``loss = -elbo(x, **kw)["elbo"].mean()`` and d loss / d theta for every parameter below this head -- what the reference's
+        trainer gets from ``loss.backward()`` (non_square_helpers.py:31-135, trainer.py:207-215) -- on the HIP kernels: encode
+        and decode with saved state, Gram + Cholesky, then the reverse passes (``head_terms_backward``, ``prior_backward``,
+        ``encode_backward``).  ``x`` is the head's input (the pre-head wrappers have no parameters; their log-jacobian
+        ``pre_logjac`` (B,) only shifts the value).  Cholesky path, ResNet couplers, standard-normal base.
+        Returns (loss: 0-dim tensor, elbo (B, 1), grads: dict parameter -> gradient)."""
+        E.require_gpu(x)
+        if np.isclose(likelihood_wt, 0.):
+            raise NotImplementedError("likelihood warm-up (likelihood_wt = 0): reconstruction-only gradients are not wired yet")
+        if self._jacobian_free or self.log_jacobian_method != "cholesky":
+            raise NotImplementedError("training gradients are built for the exact (cholesky) log-det path")
+        assert not (add_diagonal_metric_reg and add_offdiagonal_metric_reg)
+        grads = {} if grads is None else grads
+        prog, B, dev = self.program, x.shape[0], x.device
+        lam = float(self.regularization_param) if add_reconstruction else 0.0
+        with torch.no_grad():
+            x = x.contiguous()
+            z_low, low_elbo, u, ctx, pctx = prog.encode_train(x)
+            c = lambda v: torch.full((B,), v / B, dtype=torch.float32, device=dev)
+            # loss = -(1/B) sum_b [ wl (low - logdet / 2) - lam rec - wm l1 ]
+            out = self.head_terms_backward(z_low, x, g_logdet=c(0.5 * likelihood_wt),
+                                           g_l1off=c(metric_wt) if add_offdiagonal_metric_reg else None,
+                                           g_l1diag=c(metric_wt) if add_diagonal_metric_reg else None,
+                                           g_rec=c(lam) if add_reconstruction else None, grads=grads)
+            dz_low = out["dz_low"]
+            dprior = prog.prior_backward(pctx, u, c(-likelihood_wt), grads)
+            if not prog.tail.detach_before_prior:
+                dz_low = dz_low + dprior
+            prog.encode_backward(ctx, dz_low, grads)
+            rec = E.recon_sqerr(out["x_hat"], x) if add_reconstruction else None
+            l1 = out["l1_diag"] if add_diagonal_metric_reg else (out["l1_off"] if add_offdiagonal_metric_reg else None)
+            elbo = E.elbo_combine(low_elbo, out["logdet"], rec, l1, pre_logjac, likelihood_wt, self.regularization_param,
+                                  metric_wt, B, dev)
+        return -elbo.mean(), elbo, grads
 
 
 class ManifoldFlowHeadDensity(NonSquareHeadDensity):

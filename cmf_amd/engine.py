@@ -830,3 +830,24 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
     fo = dict(fo=m, fo_np=0, fo_co=HW, fo_px=1, fomode=F_RAW) if m is not None else {}
     conv_tangent(da, 0, *pn(hid), conv0.weight, 9, dx0, *pn(cin), G, hid, cin, H, W, 16, **fo, **tr)
     dz.reshape(B, geo.C, HW)[:, view.chan_off::view.chan_step][:, :cin] += primal_regroup(dx0.view(G, -1), False).view(Bp, cin, HW)[:B]
+
+
+def mlp_primal_backward(net, z, view, acts, dy, grads, dz):
+    """Primal backward of an MLP coupler network (the low-dimensional prior flows: d = 64 inputs, 32-wide layers): plain small
+    GEMMs, so they go to the BLAS library (torch.mm -> rocBLAS) with elementwise tanh' in between.  ``acts`` = the tanh outputs
+    ``net_primal`` returned; accumulates weight / bias gradients into ``grads`` and the input cotangent into ``dz``."""
+    assert net.kind == "mlp" and view.mask is None
+    lins = [m for m in net if isinstance(m, nn.Linear)]
+    B = z.shape[0]
+    rows = z.reshape(B, -1)[:, view.chan_off::view.chan_step][:, :view.cin]
+    hs = [rows] + list(acts)                                # input of every linear layer
+    d = dy.reshape(B, -1)
+    for i in reversed(range(len(lins))):
+        lin = lins[i]
+        _grad_of(grads, lin.weight).addmm_(d.t(), hs[i])
+        _grad_of(grads, lin.bias).add_(d.sum(0))
+        dh = d @ lin.weight.detach()
+        if i > 0:
+            d = dh * (1.0 - acts[i - 1] * acts[i - 1])
+        else:
+            dz.reshape(B, -1)[:, view.chan_off::view.chan_step][:, :view.cin] += dh

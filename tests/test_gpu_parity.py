@@ -560,3 +560,43 @@ def test_head_terms_parameter_gradients_match_oracle_autograd(name):
         assert rel(out["grads"][p], w.reshape(p.shape)) < 5e-4, k
         checked += 1
     assert checked >= 30
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("mini_mnist", dict(add_offdiagonal_metric_reg=True)),
+    ("mini_cifar", dict(add_diagonal_metric_reg=True, likelihood_wt=0.5, metric_wt=0.3)),
+    ("mini_mnist_small", dict(add_reconstruction=False)),
+])
+def test_loss_and_gradients_match_oracle_autograd(name, kw):
+    """f1: loss = -elbo.mean() and d loss / d theta for EVERY parameter (coupler networks above the base through encode, decode,
+    tangent stack and cross terms; the low-dimensional prior flows) against torch.autograd through the float64 CPU oracle --
+    the reference's ``loss.backward()`` (trainer.py:207-215) -- on the image fixtures (ResNet couplers)."""
+    from oracle import cmf_oracle as O
+    g, meta, cfg, dens = build(name)
+    _, schema, x_shape, ops, sd = golden_model(meta, dtype=torch.float64)
+    head = find_head(dens)
+    B = 4
+    x = g["x"][:B].double()
+    noise = torch.zeros_like(x)
+    keys = [k for k, v in sd.items() if v.is_floating_point() and any(k.endswith(s) for s in (".weight", ".bias", ".weights"))]
+    sd64 = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    want_elbo = O.elbo(sd64, ops, x, noise=noise, **kw)["elbo"]
+    want = torch.autograd.grad(-want_elbo.mean(), [sd64[k] for k in keys], allow_unused=True)
+    y, lj_pre = O.prehead(O.split_ops(ops)[0], x, noise)
+    pre = None if lj_pre is None or not torch.is_tensor(lj_pre) else lj_pre.float().reshape(-1).cuda()
+    loss, elbo, grads = head.loss_and_gradients(y.float().cuda(), pre_logjac=pre, **kw)
+    assert rel(elbo, want_elbo) < 1e-4 and rel(loss, -want_elbo.mean()) < 1e-4
+    named = dict(dens.named_parameters())
+    worst, checked = 0.0, 0
+    for k, w in zip(keys, want):
+        p = named[k]
+        if w is None:
+            assert p not in grads, k
+            continue
+        assert p in grads, k
+        err = rel(grads[p], w.reshape(p.shape))
+        worst = max(worst, err)
+        assert err < 1e-4, (k, err)
+        checked += 1
+    assert checked == len([w for w in want if w is not None]) and checked >= 40
+    print(f"{name}: {checked} parameter tensors, worst relative gradient error {worst:.2e}")
