@@ -161,35 +161,45 @@ class AffineCouplingBijection(Bijection):
     # training: decode keeping what the backward needs, and the backward of that step ------------
     def decode_train_(self, z, T):
         """``decode_`` on (z, T) in place; returns the context ``decode_backward_`` consumes: the layer input, the network's
-        outputs and activations, every layer's input tangent, the modified tangent rows before the update, the raw tangent."""
+        outputs and activations and, with a tangent stack (``T`` not None), every layer's input tangent, the modified tangent
+        rows before the update and the network's raw tangent."""
         view, maps = self.view(z.device), self.maps(z.device)
         zb = z.clone()
         y, g, acts = E.net_primal(self.net, z, view, need_acts=True)
-        saved = []
-        YT = E.net_tangent(self.net, T, view, acts, save=saved)
-        V = E.modified_rows(T, maps)
-        E.acl_tangent(T, YT, z, y, g, maps)
+        saved = V = YT = None
+        if T is not None:
+            saved = []
+            YT = E.net_tangent(self.net, T, view, acts, save=saved)
+            V = E.modified_rows(T, maps)
+            E.acl_tangent(T, YT, z, y, g, maps)
         E.acl_primal(z, y, maps, decode=True)
         return zb, y, g, acts, saved, V, YT
 
     def decode_backward_(self, Ct, dx, ctx, grads):
-        """Backward of ``decode_train_``: ``Ct`` (cotangent of the tangent stack) and ``dx`` (cotangent of the primal tensor) are
-        updated in place from "after the layer" to "before the layer"; parameter gradients accumulate into ``grads``
+        """Backward of ``decode_train_``: ``Ct`` (cotangent of the tangent stack, or None) and ``dx`` (cotangent of the primal
+        tensor) are updated in place from "after the layer" to "before the layer"; parameter gradients accumulate into ``grads``
         (dict parameter -> tensor).  Order matters: the cross terms read the cotangent of the UPDATED tangent rows."""
         zb, y, g, acts, saved, V, YT = ctx
         dev = zb.device
         view, maps = self.view(dev), self.maps(dev)
         dy = torch.zeros_like(y)
-        dg = torch.zeros_like(g) if g is not None else None
-        dz_ct = torch.zeros_like(zb)
-        E.acl_cross_terms(Ct, V, YT, zb, y, g, maps, dz_ct, dy, dg)
-        YC = E.Tangent(Ct.B, y[0].numel(), Ct.nc, self.layout, dev)
-        YC.data.zero_()
-        E.acl_cotangent(Ct, YC, zb, y, g, maps)
-        E.net_cotangent(self.net, YC, view, acts, Ct, saved=saved, grads=grads)
+        dg = None
+        if Ct is not None:
+            dg = torch.zeros_like(g) if g is not None else None
+            dz_ct = torch.zeros_like(zb)
+            E.acl_cross_terms(Ct, V, YT, zb, y, g, maps, dz_ct, dy, dg)
+            YC = E.Tangent(Ct.B, y[0].numel(), Ct.nc, self.layout, dev)
+            YC.data.zero_()
+            E.acl_cotangent(Ct, YC, zb, y, g, maps)
+            E.net_cotangent(self.net, YC, view, acts, Ct, saved=saved, grads=grads)
         E.acl_primal_backward(dx, zb, y, maps, dy, decode=True)
-        dx += dz_ct
-        E.net_primal_backward(self.net, zb, view, acts, y, g, dy, dg, grads, dx)
+        if Ct is not None:
+            dx += dz_ct
+        if self.net.kind == "resnet":
+            E.net_primal_backward(self.net, zb, view, acts, y, g, dy, dg, grads, dx)
+        else:
+            assert Ct is None, "MLP couplers under a tangent stack: the tanh layers' second-order cross terms are not built"
+            E.mlp_primal_backward(self.net, zb, view, acts, dy, grads, dx)
 
     def encode_train_(self, z, lj=None):
         """``encode_`` keeping the layer input, the network output and its activations for ``encode_backward_``."""

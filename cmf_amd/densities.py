@@ -401,13 +401,13 @@ class FlowProgram:
         return z, out.to_dense(S).contiguous()
 
     # -- training: decode with saved state, and its backward -------------------------------
-    def decode_train(self, z_low):
-        """``decode(z_low, tangents=True)`` keeping every coupling layer's context; returns (x_hat, T, ctx)."""
+    def decode_train(self, z_low, tangents=True):
+        """``decode(z_low, tangents)`` keeping every coupling layer's context; returns (x_hat, T, ctx)."""
         B, dev = z_low.shape[0], z_low.device
         N = int(np.prod(self.tail.x_shape))
         scatter = self.tail.scatter_index(dev)
         z = E.gather_primal(z_low.contiguous(), scatter, N).view(B, *self.tail.x_shape)
-        T = E.seed_tangent(B, N, E.ceil16(self.d), self.layout, scatter, self.d, dev)
+        T = E.seed_tangent(B, N, E.ceil16(self.d), self.layout, scatter, self.d, dev) if tangents else None
         ctx = []
         for m in reversed(self.layers):
             if isinstance(m, AffineCouplingBijection):
@@ -417,7 +417,7 @@ class FlowProgram:
                 idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),
                                  torch.full((n,), -1, dtype=torch.int32, device=dev)))
                 z = E.gather_primal(z, idx, 2 * n).view(B, 2 * z.shape[1], *z.shape[2:])
-                T = E.gather_tangent(T, idx, 2 * n)
+                T = E.gather_tangent(T, idx, 2 * n) if T is not None else None
                 ctx.append(n)
             else:
                 z, T = m.decode(z, T)
@@ -433,10 +433,12 @@ class FlowProgram:
             if isinstance(m, AffineCouplingBijection):
                 m.decode_backward_(Ct, dx, c, grads)
             elif isinstance(m, SplitDensity):                      # adjoint of the zero-padding: keep the first half
-                Ct = E.gather_tangent(Ct, torch.arange(c, dtype=torch.int32, device=dev), c)
+                if Ct is not None:
+                    Ct = E.gather_tangent(Ct, torch.arange(c, dtype=torch.int32, device=dev), c)
                 dx = dx.reshape(B, -1)[:, :c].reshape(B, dx.shape[1] // 2, *dx.shape[2:]).contiguous()
             else:
-                Ct = m.decode_vjp(Ct)
+                if Ct is not None:
+                    Ct = m.decode_vjp(Ct)
                 dx = m.encode(dx)                                  # x[r] = z[z2x[r]]  ->  dz = dx[x2z]
         return E.gather_primal(dx.reshape(B, -1), self.tail.gather_index(dev), self.d)
 
@@ -549,6 +551,24 @@ class NonSquareTailDensity(Density):
         return self.prior.extract_latent(x, **kwargs)
 
 
+class _ElboFunction(torch.autograd.Function):
+    """elbo (B, 1) of a NonSquareHeadDensity as one autograd node over the head's parameters: forward =
+    ``train_forward`` (saved state instead of an autograd tape), backward = ``train_backward`` on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, head, x, kw, pre, box, *params):
+        elbo, state = head.train_forward(x, pre_logjac=pre, **kw)
+        ctx.head, ctx.state, ctx.params = head, state, params
+        box["prior-dict"] = {"low-dim-x": state["z_low"]}
+        return elbo
+
+    @staticmethod
+    def backward(ctx, d_elbo):
+        grads = ctx.head.train_backward(ctx.state, d_elbo)
+        ctx.state = None                                   # the saved tangents are the bulk of the step's memory
+        return (None, None, None, None, None, *[grads.get(p) for p in ctx.params])
+
+
 class NonSquareHeadDensity(Density):
     """log p(x) ~ log p_Z(z) - 1/2 log det(J^T J) - lambda ||x_hat - x||^2 - w_M * g-term
     (non_square.py:22-129), J the Jacobian of the decoder z -> x_hat at z = encode(x)."""
@@ -582,16 +602,23 @@ class NonSquareHeadDensity(Density):
         return self._program
 
     # ------------------------------------------------------------------------------------------
-    def _check_grad(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError(
-                "cmf_amd: the HIP log-density path is forward-only in this build (reverse-mode kernels are the "
-                "next scope row, SURVEY.md f1); call it under torch.no_grad()")
+    def _wants_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     def _elbo(self, x, add_reconstruction=True, add_diagonal_metric_reg=False, add_offdiagonal_metric_reg=False,
               likelihood_wt=1., metric_wt=1., visualization=False, ood=False, test_metric=False, _pre_logjac=None):
         E.require_gpu(x)
-        self._check_grad()
+        if self._wants_grad():
+            # autograd mode (the reference's loss.backward(), trainer.py:213): the elbo comes back attached to a custom
+            # autograd node whose backward runs the reverse passes on the HIP kernels and hands d loss / d theta to autograd
+            if ood or visualization:
+                raise NotImplementedError("ood / visualization under autograd: call them under torch.no_grad()")
+            params = [p for p in self.parameters() if p.requires_grad]
+            kw = dict(add_reconstruction=add_reconstruction, add_diagonal_metric_reg=add_diagonal_metric_reg,
+                      add_offdiagonal_metric_reg=add_offdiagonal_metric_reg, likelihood_wt=likelihood_wt, metric_wt=metric_wt)
+            box = {}
+            elbo = _ElboFunction.apply(self, x, kw, _pre_logjac, box, *params)
+            return {"elbo": elbo, "prior-dict": box["prior-dict"]}
         if ood:
             assert self.log_jacobian_method == "cholesky"
         if add_reconstruction:
@@ -728,64 +755,102 @@ class NonSquareHeadDensity(Density):
         return x_hat, T.to_dense(self.program.d).contiguous()
 
 
-    def head_terms_backward(self, z_low, x, g_logdet=None, g_l1off=None, g_l1diag=None, g_rec=None, grads=None):
-        """Training building block: parameter gradients and the latent cotangent of
-            sum_b  g_logdet[b] logdet(J^T J)_b + g_l1off[b] sum_{i!=j}|G_ij| + g_l1diag[b] sum_i |G_ii| + g_rec[b] ||x_hat_b - x_b||^2
-        at FIXED z_low -- the head terms of non_square.py:64-129 that depend on the decode side (the encode / prior chain that
-        produces z_low is not differentiated here).  ResNet couplers only.  Returns a dict with the forward values, ``dz_low``
-        (B, d) and ``grads`` (parameter -> gradient, accumulated into when passed in)."""
+    # ------------------------------------------------------------------------------------------
+    # training: forward with saved state, backward on the HIP kernels
+    # ------------------------------------------------------------------------------------------
+    def head_terms_forward(self, z_low, tangents=True):
+        """Decode (with the Jacobian stack) keeping every layer's context, Gram + Cholesky; returns the state
+        ``head_terms_backward`` consumes."""
         E.require_gpu(z_low)
-        grads = {} if grads is None else grads
-        d = self.program.d
         with torch.no_grad():
-            x_hat, T, ctx = self.program.decode_train(z_low.detach())
-            gr = E.gram_cholesky(T, d)
-            if int(gr.fail[0].item()) != 0:
-                raise RuntimeError("J^T J is not positive definite at the first attempt: the jittered retries are not differentiated")
-            Ct = E.gram_backward(T, gr.jtj, g_logdet, g_l1off, g_l1diag)
-            B = z_low.shape[0]
+            x_hat, T, ctx = self.program.decode_train(z_low.detach(), tangents)
+            gr = None
+            if tangents:
+                gr = E.gram_cholesky(T, self.program.d)
+                if int(gr.fail[0].item()) != 0:
+                    raise RuntimeError("J^T J is not positive definite at the first attempt: the jittered retries are not differentiated")
+        return {"x_hat": x_hat, "T": T, "ctx": ctx, "gram": gr}
+
+    def head_terms_backward(self, z_low, x, g_logdet=None, g_l1off=None, g_l1diag=None, g_rec=None, grads=None, state=None):
+        """Parameter gradients and the latent cotangent of
+            sum_b  g_logdet[b] logdet(J^T J)_b + g_l1off[b] sum_{i!=j}|G_ij| + g_l1diag[b] sum_i |G_ii| + g_rec[b] ||x_hat_b - x_b||^2
+        at FIXED z_low -- the head terms of non_square.py:64-129 that depend on the decode side.  ResNet couplers under a
+        tangent stack.  Returns a dict with the forward values, ``dz_low`` (B, d) and ``grads`` (parameter -> gradient,
+        accumulated into when passed in)."""
+        grads = {} if grads is None else grads
+        tangents = any(t is not None for t in (g_logdet, g_l1off, g_l1diag))
+        st = state if state is not None else self.head_terms_forward(z_low, tangents)
+        x_hat, T, gr = st["x_hat"], st["T"], st["gram"]
+        B = x_hat.shape[0]
+        with torch.no_grad():
+            Ct = E.gram_backward(T, gr.jtj, g_logdet, g_l1off, g_l1diag) if tangents else None
             dx = torch.zeros_like(x_hat)
             if g_rec is not None:
                 dx = 2.0 * g_rec.to(torch.float32).view(B, *([1] * (x_hat.dim() - 1))) * (x_hat - x)
-            dz = self.program.decode_backward(ctx, Ct, dx, grads)
-        return {"x_hat": x_hat, "logdet": gr.logdet, "l1_off": gr.l1_off, "l1_diag": gr.l1_diag, "dz_low": dz, "grads": grads}
+            dz = self.program.decode_backward(st["ctx"], Ct, dx, grads)
+        out = {"x_hat": x_hat, "dz_low": dz, "grads": grads}
+        if gr is not None:
+            out.update(logdet=gr.logdet, l1_off=gr.l1_off, l1_diag=gr.l1_diag)
+        return out
 
-
-    def loss_and_gradients(self, x, add_reconstruction=True, add_diagonal_metric_reg=False, add_offdiagonal_metric_reg=False,
-                           likelihood_wt=1., metric_wt=1., pre_logjac=None, grads=None):
-        """``loss = -elbo(x, **kw)["elbo"].mean()`` and d loss / d theta for every parameter below this head -- what the reference's
-        trainer gets from ``loss.backward()`` (non_square_helpers.py:31-135, trainer.py:207-215) -- on the HIP kernels: encode
-        and decode with saved state, Gram + Cholesky, then the reverse passes (``head_terms_backward``, ``prior_backward``,
-        ``encode_backward``).  ``x`` is the head's input (the pre-head wrappers have no parameters; their log-jacobian
-        ``pre_logjac`` (B,) only shifts the value).  Cholesky path, ResNet couplers, standard-normal base.
-        Returns (loss: 0-dim tensor, elbo (B, 1), grads: dict parameter -> gradient)."""
+    def train_forward(self, x, add_reconstruction=True, add_diagonal_metric_reg=False, add_offdiagonal_metric_reg=False,
+                      likelihood_wt=1., metric_wt=1., pre_logjac=None):
+        """Forward half of a training step: ``elbo`` (B, 1) exactly as ``_elbo`` computes it on the exact path, plus the state
+        ``train_backward`` needs (every layer's input, activations, input tangents: ~17 hidden tangent tensors per ResNet
+        coupler stay alive -- 131 GB for MNIST d = 64 at the reference's 64 samples per GPU).  ``x`` = the head's input."""
         E.require_gpu(x)
-        if np.isclose(likelihood_wt, 0.):
-            raise NotImplementedError("likelihood warm-up (likelihood_wt = 0): reconstruction-only gradients are not wired yet")
-        if self._jacobian_free or self.log_jacobian_method != "cholesky":
+        if self._jacobian_free or (self.training and self.log_jacobian_method != "cholesky"):
             raise NotImplementedError("training gradients are built for the exact (cholesky) log-det path")
         assert not (add_diagonal_metric_reg and add_offdiagonal_metric_reg)
-        grads = {} if grads is None else grads
         prog, B, dev = self.program, x.shape[0], x.device
-        lam = float(self.regularization_param) if add_reconstruction else 0.0
+        want_lik = not np.isclose(likelihood_wt, 0.)
+        if want_lik and any(isinstance(m, AffineCouplingBijection) and m.net.kind != "resnet" for m in prog.layers):
+            raise NotImplementedError("training gradients through MLP couplers above the base (2-D / tabular configs): the tanh "
+                                      "layers' second-order cross terms of the tangent pass are not built")
         with torch.no_grad():
             x = x.contiguous()
             z_low, low_elbo, u, ctx, pctx = prog.encode_train(x)
-            c = lambda v: torch.full((B,), v / B, dtype=torch.float32, device=dev)
-            # loss = -(1/B) sum_b [ wl (low - logdet / 2) - lam rec - wm l1 ]
-            out = self.head_terms_backward(z_low, x, g_logdet=c(0.5 * likelihood_wt),
-                                           g_l1off=c(metric_wt) if add_offdiagonal_metric_reg else None,
-                                           g_l1diag=c(metric_wt) if add_diagonal_metric_reg else None,
-                                           g_rec=c(lam) if add_reconstruction else None, grads=grads)
+            head = self.head_terms_forward(z_low, tangents=want_lik)
+            gr = head["gram"]
+            rec = E.recon_sqerr(head["x_hat"], x) if add_reconstruction else None
+            l1 = None
+            if want_lik:
+                l1 = gr.l1_diag if add_diagonal_metric_reg else (gr.l1_off if add_offdiagonal_metric_reg else None)
+            elbo = E.elbo_combine(low_elbo if want_lik else None, gr.logdet if want_lik else None, rec, l1, pre_logjac,
+                                  likelihood_wt, self.regularization_param, metric_wt, B, dev)
+        state = dict(x=x, z_low=z_low, u=u, ctx=ctx, pctx=pctx, head=head, want_lik=want_lik, rec=add_reconstruction,
+                     diag=add_diagonal_metric_reg, off=add_offdiagonal_metric_reg, wl=float(likelihood_wt), wm=float(metric_wt))
+        return elbo, state
+
+    def train_backward(self, state, d_elbo, grads=None):
+        """Backward half: ``d_elbo`` (B,) or (B, 1) = d loss / d elbo_b (``-1/B`` for ``loss = -elbo.mean()``).  Accumulates
+        d loss / d theta of every parameter below this head into ``grads`` (dict parameter -> tensor) and returns it."""
+        grads = {} if grads is None else grads
+        prog = self.program
+        w = d_elbo.detach().reshape(-1).to(torch.float32)
+        lam = float(self.regularization_param)
+        with torch.no_grad():
+            # elbo_b = wl (low_b - logdet_b / 2) - lam rec_b - wm l1_b
+            lik = state["want_lik"]
+            out = self.head_terms_backward(state["z_low"], state["x"],
+                                           g_logdet=w * (-0.5 * state["wl"]) if lik else None,
+                                           g_l1off=w * (-state["wm"]) if lik and state["off"] else None,
+                                           g_l1diag=w * (-state["wm"]) if lik and state["diag"] else None,
+                                           g_rec=w * (-lam) if state["rec"] else None, grads=grads, state=state["head"])
             dz_low = out["dz_low"]
-            dprior = prog.prior_backward(pctx, u, c(-likelihood_wt), grads)
-            if not prog.tail.detach_before_prior:
-                dz_low = dz_low + dprior
-            prog.encode_backward(ctx, dz_low, grads)
-            rec = E.recon_sqerr(out["x_hat"], x) if add_reconstruction else None
-            l1 = out["l1_diag"] if add_diagonal_metric_reg else (out["l1_off"] if add_offdiagonal_metric_reg else None)
-            elbo = E.elbo_combine(low_elbo, out["logdet"], rec, l1, pre_logjac, likelihood_wt, self.regularization_param,
-                                  metric_wt, B, dev)
+            if lik:
+                dprior = prog.prior_backward(state["pctx"], state["u"], w * state["wl"], grads)
+                if not prog.tail.detach_before_prior:
+                    dz_low = dz_low + dprior
+            prog.encode_backward(state["ctx"], dz_low, grads)
+        return grads
+
+    def loss_and_gradients(self, x, pre_logjac=None, grads=None, **kwargs):
+        """``loss = -elbo(x, **kw)["elbo"].mean()`` and d loss / d theta for every parameter below this head -- what the reference's
+        trainer gets from ``loss.backward()`` (non_square_helpers.py:31-135, trainer.py:207-215).  Returns (loss, elbo, grads)."""
+        elbo, state = self.train_forward(x, pre_logjac=pre_logjac, **kwargs)
+        B = elbo.shape[0]
+        grads = self.train_backward(state, torch.full((B,), -1.0 / B, device=elbo.device), grads)
         return -elbo.mean(), elbo, grads
 
 

@@ -600,3 +600,40 @@ def test_loss_and_gradients_match_oracle_autograd(name, kw):
         checked += 1
     assert checked == len([w for w in want if w is not None]) and checked >= 40
     print(f"{name}: {checked} parameter tensors, worst relative gradient error {worst:.2e}")
+    # the same through autograd, as the reference trainer drives it: elbo -> loss -> loss.backward() -> p.grad
+    dens.train()
+    dens.zero_grad()
+    with torch.enable_grad():
+        out = inner(dens, "noise" in g).elbo(g["x"][:B].float().cuda(), **kw)
+        assert out["elbo"].requires_grad and rel(out["elbo"], want_elbo) < 1e-4
+        (-out["elbo"].mean()).backward()
+    for k, w in zip(keys, want):
+        if w is not None:
+            assert rel(named[k].grad, w.reshape(named[k].shape)) < 1e-4, k
+        else:
+            assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0
+
+
+def test_training_steps_reduce_the_loss():
+    """Five optimiser steps on a fixed mini-batch through the reference's training closure (``get_non_square_train_metrics``,
+    ``loss.backward()``) with the flat-buffer Adam: the loss goes down, and warm-up epochs (likelihood_wt = 0) run too."""
+    import cmf_amd
+    from cmf_amd.optim import FlatOptimizer
+    g, meta, cfg, dens = build("mini_mnist")
+    dens.train()
+    cfg = dict(cfg, g_ij_loss=True, g_kk_loss=False)
+    train_metrics, intro, early = cmf_amd.get_non_square_train_metrics(cfg)
+    opt = FlatOptimizer(dens.parameters(), opt="adam", lr=1e-3, max_grad_norm=100.0)
+    x0 = g["x"][:8].float().cuda()
+    losses = []
+    for it in range(5):
+        opt.zero_grad()
+        loss = train_metrics(dens, x0.clone(), 10_000)["loss"]          # far past every warm-up boundary
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    opt.zero_grad()
+    warm = train_metrics(dens, x0.clone(), 0)["loss"]                   # epoch 0: reconstruction-only objective
+    warm.backward()
+    assert float(opt.grad.abs().max()) > 0
