@@ -266,7 +266,8 @@ def conv_tangent_wgrad(x_t, x_off, x_np, x_ci, x_px, gy_t, gy_off, y_np, y_co, y
     if TIMER is None:
         return launch()
     px = float(H) * W * nc * np_
-    TIMER.wrap(f"conv_wgrad_t{taps}_ci{cin}_co{cout}", 2.0 * cin * cout * taps * px, 4.0 * px * (cin + cout), launch)
+    TIMER.wrap(f"conv_wgrad_t{taps}_ci{cin}_co{cout}" + ("_primal" if fmode == F_SELF_RELU else ""), 2.0 * cin * cout * taps * px,
+               4.0 * px * (cin + cout), launch)
 
 
 def primal_regroup(t, to_grouped):

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Training step (forward + backward + flat Adam) of the C3 / C4 model on one MI355X: the secondary metric of SURVEY 8d
+("train-mode fwd+bwd steps/s").  The reference trains MNIST with 64 samples per GPU (C4).
+
+  python tools/bench_train.py [--batch 64] [--steps 3]
+"""
+import argparse, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
+args = ap.parse_args()
+import bench
+from cmf_amd import engine as E
+from cmf_amd.optim import FlatOptimizer
+dev = torch.device("cuda", 0)
+cfg, schema, shape, sd, density = bench.make_model(dev)
+density.train()
+opt = FlatOptimizer(density.parameters(), opt="adam", lr=1e-4)
+x = bench.synth_batch(shape, args.batch, 0, dev)
+kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=True, likelihood_wt=1., metric_wt=1.)
+
+def step():
+    opt.zero_grad()
+    loss = -density.elbo(x.clone(), **kw)["elbo"].mean()
+    loss.backward()
+    opt.step()
+    return loss
+
+for _ in range(args.warmup):
+    step()
+torch.cuda.synchronize()
+torch.cuda.reset_peak_memory_stats()
+E.TIMER = E.KernelTimer(lambda name: True)
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    loss = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+by = E.TIMER.by_name() if hasattr(E.TIMER, "by_name") else {}
+E.TIMER = None
+print(f"train step B={args.batch}: {1e3*dt:.1f} ms  ({args.batch/dt:.1f} samples/s, {1/dt:.3f} steps/s)  loss {float(loss.detach()):.1f}  "
+      f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+rows = sorted(by.items(), key=lambda kv: -kv[1][1])[:12] if by else []
+for name, (n, ms, fl, _) in rows:
+    print(f"  {name:40s} {n // args.steps:5d} launches/step  {ms/args.steps:9.2f} ms/step  {fl/max(ms,1e-9)/1e9:7.1f} TFLOP/s")
