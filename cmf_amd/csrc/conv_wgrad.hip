@@ -137,6 +137,7 @@ struct WCol {
   float f[2][3];
 };
 
+template <bool SELF>   // SELF: the input's own relu instead of a factor tensor (a run-time select here cost 100+ branches and vmcnt(0) waits)
 __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_kernel(cmf_conv_tangent_args a, const float* __restrict__ gy,
                                                                float* __restrict__ ws, int co0, int ci0, int nrows) {
   const int lane = threadIdx.x & 63;
@@ -146,8 +147,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_kernel(cmf_conv_tangent_
   const int W = a.W, H = a.H, nsl = a.nc / 16;
   const long long xsl = a.x_sl ? a.x_sl : 16, ysl = a.y_sl ? a.y_sl : 16;
   const int fgrp = a.f_group > 1 ? a.f_group : 1;
-  const bool self = a.fmode == CMF_F_SELF_RELU;
-  const bool has_f = a.f != nullptr && a.fmode != CMF_F_NONE && !self;
+  const bool has_f = !SELF && a.f != nullptr && a.fmode != CMF_F_NONE;
   // factor = c0 + c1 [f > 0] + c2 f + c3 f^2  (NONE: 1, RELU: [f > 0], TANH: 1 - f^2, RAW: f) -- branch-free
   const float fc0 = (!has_f || a.fmode == CMF_F_TANH) ? 1.f : 0.f, fc1 = (has_f && a.fmode == CMF_F_RELU) ? 1.f : 0.f;
   const float fc2 = (has_f && a.fmode == CMF_F_RAW) ? 1.f : 0.f, fc3 = (has_f && a.fmode == CMF_F_TANH) ? -1.f : 0.f;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_kernel(cmf_conv_tangent_
         const float f = cs.f[il][dy];
         const float m = fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cs.v[il][dy][k] = ok ? (self ? fmaxf(cs.v[il][dy][k], 0.f) : cs.v[il][dy][k] * m) : 0.f;
+        for (int k = 0; k < 4; ++k) cs.v[il][dy][k] = ok ? (SELF ? fmaxf(cs.v[il][dy][k], 0.f) : cs.v[il][dy][k] * m) : 0.f;
       }
 #pragma unroll
     for (int k = 0; k < 4; ++k) g[k] = gbit ? g[k] : 0.f;
@@ -324,7 +324,10 @@ extern "C" int cmf_conv_tangent_wgrad(const cmf_conv_tangent_args* a, const floa
   hipStream_t s = (hipStream_t)stream;
   for (int co0 = 0; co0 < a->cout; co0 += 64)
     for (int ci0 = 0; ci0 < a->cin; ci0 += 64) {
-      if (a->taps == 9 && !simple) hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3(grid), dim3(512), 0, s, *a, gy, ws, co0, ci0, (int)nrows);
+      if (a->taps == 9 && !simple && a->fmode == CMF_F_SELF_RELU)
+        hipLaunchKernelGGL(conv_wgrad3x3_kernel<true>, dim3(grid), dim3(512), 0, s, *a, gy, ws, co0, ci0, (int)nrows);
+      else if (a->taps == 9 && !simple)
+        hipLaunchKernelGGL(conv_wgrad3x3_kernel<false>, dim3(grid), dim3(512), 0, s, *a, gy, ws, co0, ci0, (int)nrows);
       else if (a->taps == 9) hipLaunchKernelGGL(conv_wgrad_kernel<9>, dim3(grid), dim3(512), 0, s, *a, gy, ws, co0, ci0, nkb);
       else hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(grid), dim3(512), 0, s, *a, gy, ws, co0, ci0, nkb);
       CMF_LAUNCH_CHECK();
