@@ -626,12 +626,13 @@ def test_training_steps_reduce_the_loss():
     opt = FlatOptimizer(dens.parameters(), opt="adam", lr=1e-3, max_grad_norm=100.0)
     x0 = g["x"][:8].float().cuda()
     losses = []
+    from cmf_amd.training import train_batch
     for it in range(5):
-        opt.zero_grad()
-        loss = train_metrics(dens, x0.clone(), 10_000)["loss"]          # far past every warm-up boundary
-        loss.backward()
-        opt.step()
-        losses.append(float(loss.detach()))
+        out = train_batch(dens, x0.clone(), 10_000, train_metrics, [opt])      # far past every warm-up boundary
+        losses.append(float(out["metrics"]["loss"].detach()))
+    ref_opt = torch.optim.Adam(dens.parameters(), lr=1e-3)                     # a torch optimiser drives the same path
+    out = train_batch(dens, x0.clone(), 10_000, train_metrics, [ref_opt], max_grad_norm=100.0)
+    losses.append(float(out["metrics"]["loss"].detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     opt.zero_grad()
     warm = train_metrics(dens, x0.clone(), 0)["loss"]                   # epoch 0: reconstruction-only objective
