@@ -191,15 +191,15 @@ class AffineCouplingBijection(Bijection):
             YC = E.Tangent(Ct.B, y[0].numel(), Ct.nc, self.layout, dev)
             YC.data.zero_()
             E.acl_cotangent(Ct, YC, zb, y, g, maps)
-            E.net_cotangent(self.net, YC, view, acts, Ct, saved=saved, grads=grads)
+            cross = {}
+            E.net_cotangent(self.net, YC, view, acts, Ct, saved=saved, grads=grads, cross=cross)
         E.acl_primal_backward(dx, zb, y, maps, dy, decode=True)
         if Ct is not None:
             dx += dz_ct
         if self.net.kind == "resnet":
             E.net_primal_backward(self.net, zb, view, acts, y, g, dy, dg, grads, dx)
         else:
-            assert Ct is None, "MLP couplers under a tangent stack: the tanh layers' second-order cross terms are not built"
-            E.mlp_primal_backward(self.net, zb, view, acts, dy, grads, dx)
+            E.mlp_primal_backward(self.net, zb, view, acts, dy, grads, dx, dh_extra=cross if Ct is not None else None)
 
     def encode_train_(self, z, lj=None):
         """``encode_`` keeping the layer input, the network output and its activations for ``encode_backward_``."""
@@ -399,6 +399,22 @@ class AffineBijection(Bijection):
 
     def decode_(self, z, lj=None):
         E.affine_prior(z, self.log_scale, self.shift, decode=True, lj=lj)
+
+    def encode_train_(self, z, lj=None):
+        xb = z.clone()
+        self.encode_(z, lj)
+        return xb
+
+    def encode_backward_(self, dz, ctx, grads, dlj=None):
+        """u = x e^{ls} + sh, lj = sum ls (two parameters of d elements each: elementwise host ops)."""
+        es = torch.exp(self.log_scale.detach()).reshape(1, -1)
+        d2, x2 = dz.view(dz.shape[0], -1), ctx.view(dz.shape[0], -1)
+        gls = (d2 * x2 * es).sum(0)
+        if dlj is not None:
+            gls = gls + dlj.sum()
+        E._grad_of(grads, self.log_scale).view(-1).add_(gls)
+        E._grad_of(grads, self.shift).view(-1).add_(d2.sum(0))
+        d2.mul_(es)
 
     def _x_to_z(self, x):
         E.require_gpu(x)

@@ -53,6 +53,32 @@ __global__ __launch_bounds__(1024) void channel_sum_kernel(const float* __restri
   if (threadIdx.x == 0) out[c] += acc;
 }
 
+// MLP couplers (tanh layers): the tangent rule of layer i+1 reads phi_i = 1 - h_i^2 of the PRIMAL activation, so the reverse
+// sweep has a second-order term.  Given the unmasked cotangent ct = W_{i+1}^T c_{i+1} (rows = features, fmajor / panel tangent
+// layout) and the saved raw tangent x_i of the same rows:   c_i = phi_i ct  (in place),   dh_i[b][f] += -2 h_i sum_col ct x_i.
+// One wavefront per (sample, feature).
+__global__ __launch_bounds__(256) void tanh_cross_terms_kernel(float* __restrict__ c, long long c_b, long long c_r,
+                                                               const float* __restrict__ x, long long x_b, long long x_r,
+                                                               const float* __restrict__ h, float* __restrict__ dh, int F, int nc,
+                                                               long long n_rows) {
+  const long long bf = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bf >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int f = (int)(bf % F);
+  const long long b = bf / F;
+  const float hv = h[b * F + f], phi = 1.f - hv * hv;
+  float* cp = c + b * c_b + (long long)f * c_r;
+  const float* xp = x + b * x_b + (long long)f * x_r;
+  float acc = 0.f;
+  for (int k = lane; k < nc; k += 64) {
+    const float ct = cp[k];
+    acc += ct * xp[k];
+    cp[k] = phi * ct;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dh[b * F + f] += -2.f * hv * acc;
+}
+
 }  // namespace
 
 extern "C" int cmf_stanh_backward(const float* dy, const float* dg, const float* y, const float* g, const float* sw,
@@ -69,6 +95,16 @@ extern "C" int cmf_channel_sum(const float* t, long long t_np, long long t_c, lo
   if ((uintptr_t)t % 16 || (t_np | t_c | t_px | t_sl) % 4) return CMF_EINVAL;
   hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, t, t_np, t_c, t_px, t_sl ? t_sl : 16, np, npx,
                      nc, out);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cmf_tanh_cross_terms(float* c, long long c_b, long long c_r, const float* x, long long x_b, long long x_r,
+                                    const float* h, float* dh, int F, int B, int nc, void* stream) {
+  if (!c || !x || !h || !dh || F <= 0 || B <= 0 || nc <= 0) return CMF_EINVAL;
+  const long long n_rows = (long long)B * F;
+  hipLaunchKernelGGL(tanh_cross_terms_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, c, c_b, c_r, x,
+                     x_b, x_r, h, dh, F, nc, n_rows);
   CMF_LAUNCH_CHECK();
   return 0;
 }

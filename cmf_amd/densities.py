@@ -463,10 +463,8 @@ class FlowProgram:
         lj = torch.zeros(B, dtype=torch.float32, device=x.device)
         pctx = []
         for m in self.prior:
-            if isinstance(m, AffineCouplingBijection):
+            if isinstance(m, (AffineCouplingBijection, AffineBijection)):
                 pctx.append((m, m.encode_train_(u, lj)))
-            elif isinstance(m, AffineBijection):
-                raise NotImplementedError("training gradients through the 2-D AffineBijection prior are not built")
         if self.gaussian._nonstandard():
             raise NotImplementedError("training gradients with a non-standard base Gaussian are not built")
         self.gaussian.logprob_accumulate(u, lj)
@@ -804,9 +802,6 @@ class NonSquareHeadDensity(Density):
         assert not (add_diagonal_metric_reg and add_offdiagonal_metric_reg)
         prog, B, dev = self.program, x.shape[0], x.device
         want_lik = not np.isclose(likelihood_wt, 0.)
-        if want_lik and any(isinstance(m, AffineCouplingBijection) and m.net.kind != "resnet" for m in prog.layers):
-            raise NotImplementedError("training gradients through MLP couplers above the base (2-D / tabular configs): the tanh "
-                                      "layers' second-order cross terms of the tangent pass are not built")
         with torch.no_grad():
             x = x.contiguous()
             z_low, low_elbo, u, ctx, pctx = prog.encode_train(x)

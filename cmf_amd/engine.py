@@ -699,7 +699,7 @@ def _grad_of(grads, weight):
     return g
 
 
-def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None):
+def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None, cross=None):
     """Reverse sweep through the coupler network (the adjoint of ``net_tangent``): ``YC`` is the cotangent of the network's
     raw output; the cotangent of its input is ACCUMULATED into the rows of ``Ct`` the network reads (``view``).
     The adjoint of "factor, then conv" is "transposed conv, then factor": transposed / tap-flipped packs
@@ -707,7 +707,8 @@ def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None):
     stored tensor is the true cotangent of a layer output.
     Training (``saved`` = the list ``net_tangent(save=)`` filled, ``grads`` = dict parameter -> gradient tensor): the weight
     gradient of every layer, ``dW += sum c_out (x) F x_in`` (``cmf_conv_tangent_wgrad``), is accumulated into ``grads``.
-    Biases do not act on tangents and get no gradient here."""
+    Biases do not act on tangents and get no gradient here.  ``cross`` (MLP networks, a dict): receives, per hidden layer
+    index, the cotangent of the primal tanh activation from the tangent rule's second-order term (``cmf_tanh_cross_terms``)."""
     geo, B, nc, dev = view.geom, Ct.B, Ct.nc, Ct.data.device
     f32 = dict(transpose=True, precision="f32")
     train = saved is not None
@@ -766,6 +767,18 @@ def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None):
             fm = dict(fmode=F_TANH, f=acts[i - 1], f_np=0, f_ci=1, f_px=lin.in_features) if i > 0 else {}
             conv_tangent_wgrad(xin.data, 0, 0, B * nc, nc, c_t, 0, 0, B * nc, nc, _grad_of(grads, lin.weight), 1, 1, lin.in_features,
                                lin.out_features, 1, B, nc, **fm)
+        if train and i > 0 and cross is not None:
+            # training: the unmasked product first, then phi . (in place) together with the second-order term
+            #   d h_{i-1} += -2 h_{i-1} sum_col (W_i^T c_i) x_{i-1}      (phi_{i-1} = 1 - h_{i-1}^2 is read by layer i's tangent rule)
+            out = Tangent(B, lin.in_features, nc, "fmajor", dev)
+            conv_tangent(c_t, 0, 0, B * nc, nc, lin.weight, 1, out.data, 0, B * nc, nc, 1, cin, lin.in_features, 1, B, nc, **f32)
+            dh = torch.zeros_like(acts[i - 1])
+            _lib.check(_lib.load().cmf_tanh_cross_terms(_p(out.data), out.t_b, out.t_r, _p(saved[i].data), saved[i].t_b, saved[i].t_r,
+                                                        _p(acts[i - 1]), _p(dh), lin.in_features, B, nc, _stream()),
+                       "cmf_tanh_cross_terms")
+            cross[i - 1] = dh
+            c_t, cin = out.data, lin.in_features
+            continue
         if i == 0:
             off = view.chan_off * B * nc
             conv_tangent(c_t, 0, 0, B * nc, nc, lin.weight, 1, Ct.data, 0, view.chan_step * B * nc, nc, 1, cin, view.cin, 1, B, nc,
@@ -833,7 +846,7 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
     dz.reshape(B, geo.C, HW)[:, view.chan_off::view.chan_step][:, :cin] += primal_regroup(dx0.view(G, -1), False).view(Bp, cin, HW)[:B]
 
 
-def mlp_primal_backward(net, z, view, acts, dy, grads, dz):
+def mlp_primal_backward(net, z, view, acts, dy, grads, dz, dh_extra=None):
     """Primal backward of an MLP coupler network (the low-dimensional prior flows: d = 64 inputs, 32-wide layers): plain small
     GEMMs, so they go to the BLAS library (torch.mm -> rocBLAS) with elementwise tanh' in between.  ``acts`` = the tanh outputs
     ``net_primal`` returned; accumulates weight / bias gradients into ``grads`` and the input cotangent into ``dz``."""
@@ -849,6 +862,8 @@ def mlp_primal_backward(net, z, view, acts, dy, grads, dz):
         _grad_of(grads, lin.bias).add_(d.sum(0))
         dh = d @ lin.weight.detach()
         if i > 0:
+            if dh_extra is not None and (i - 1) in dh_extra:            # second-order term of the tangent pass (net_cotangent)
+                dh = dh + dh_extra[i - 1]
             d = dh * (1.0 - acts[i - 1] * acts[i - 1])
         else:
             dz.reshape(B, -1)[:, view.chan_off::view.chan_step][:, :view.cin] += dh

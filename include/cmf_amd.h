@@ -258,6 +258,12 @@ int cmf_hutch_cg(const float* jtj, const float* eps, int d, int S, int B, int ma
  * dg (cotangent of g, from cmf_acl_cross_terms) may be NULL; dsw / dsb may be NULL.                                */
 int cmf_stanh_backward(const float* dy, const float* dg, const float* y, const float* g, const float* sw,
                        const float* sb, float* du, float* dsw, float* dsb, int B, int C, int HW, void* stream);
+/* Second-order term of the tanh MLP couplers' tangent pass (get_linear_jvp + the tanh rule, jvp_layers.py:38-53): layer i+1
+ * reads phi_i = 1 - h_i^2 of the primal activation h (B, F).  c holds the UNMASKED cotangent W_{i+1}^T c_{i+1} of the rows
+ * (element (b, f, col) at c + b*c_b + f*c_r + col), x the saved raw tangent of the same rows:
+ *     c <- phi c  (in place: the cotangent of layer i's raw output);   dh[b][f] += -2 h sum_col c_old x                    */
+int cmf_tanh_cross_terms(float* c, long long c_b, long long c_r, const float* x, long long x_b, long long x_r,
+                         const float* h, float* dh, int F, int B, int nc, void* stream);
 /* out[c] += sum_{n, px, col} t(n, c, px, col) over a tangent-layout tensor (element at n*t_np + c*t_c + px*t_px +
  * (col/16)*t_sl + col%16, t_sl = 0 meaning 16): the bias gradient of nn.Conv2d / nn.Linear.                        */
 int cmf_channel_sum(const float* t, long long t_np, long long t_c, long long t_px, long long t_sl, int np, int C,

@@ -566,6 +566,10 @@ def test_head_terms_parameter_gradients_match_oracle_autograd(name):
     ("mini_mnist", dict(add_offdiagonal_metric_reg=True)),
     ("mini_cifar", dict(add_diagonal_metric_reg=True, likelihood_wt=0.5, metric_wt=0.3)),
     ("mini_mnist_small", dict(add_reconstruction=False)),
+    ("c1_sphere", dict(add_offdiagonal_metric_reg=True)),
+    ("c1_sphere_d2", dict(add_offdiagonal_metric_reg=True, likelihood_wt=0.7)),
+    ("c2a_power", dict(add_diagonal_metric_reg=True, metric_wt=0.2)),
+    ("c2b_hepmass", dict(add_offdiagonal_metric_reg=True)),
 ])
 def test_loss_and_gradients_match_oracle_autograd(name, kw):
     """f1: loss = -elbo.mean() and d loss / d theta for EVERY parameter (coupler networks above the base through encode, decode,
@@ -578,7 +582,8 @@ def test_loss_and_gradients_match_oracle_autograd(name, kw):
     B = 4
     x = g["x"][:B].double()
     noise = torch.zeros_like(x)
-    keys = [k for k, v in sd.items() if v.is_floating_point() and any(k.endswith(s) for s in (".weight", ".bias", ".weights"))]
+    named = dict(dens.named_parameters())
+    keys = [k for k, v in sd.items() if v.is_floating_point() and k in named]
     sd64 = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
     want_elbo = O.elbo(sd64, ops, x, noise=noise, **kw)["elbo"]
     want = torch.autograd.grad(-want_elbo.mean(), [sd64[k] for k in keys], allow_unused=True)
@@ -586,19 +591,18 @@ def test_loss_and_gradients_match_oracle_autograd(name, kw):
     pre = None if lj_pre is None or not torch.is_tensor(lj_pre) else lj_pre.float().reshape(-1).cuda()
     loss, elbo, grads = head.loss_and_gradients(y.float().cuda(), pre_logjac=pre, **kw)
     assert rel(elbo, want_elbo) < 1e-4 and rel(loss, -want_elbo.mean()) < 1e-4
-    named = dict(dens.named_parameters())
     worst, checked = 0.0, 0
     for k, w in zip(keys, want):
         p = named[k]
-        if w is None:
-            assert p not in grads, k
+        if w is None or float(w.abs().max()) == 0.0:
+            assert p not in grads or float(grads[p].abs().max()) == 0.0, k
             continue
         assert p in grads, k
         err = rel(grads[p], w.reshape(p.shape))
         worst = max(worst, err)
         assert err < 1e-4, (k, err)
         checked += 1
-    assert checked == len([w for w in want if w is not None]) and checked >= 40
+    assert checked >= (40 if len(x_shape) == 3 else 10)
     print(f"{name}: {checked} parameter tensors, worst relative gradient error {worst:.2e}")
     # the same through autograd, as the reference trainer drives it: elbo -> loss -> loss.backward() -> p.grad
     dens.train()
@@ -608,7 +612,7 @@ def test_loss_and_gradients_match_oracle_autograd(name, kw):
         assert out["elbo"].requires_grad and rel(out["elbo"], want_elbo) < 1e-4
         (-out["elbo"].mean()).backward()
     for k, w in zip(keys, want):
-        if w is not None:
+        if w is not None and float(w.abs().max()) > 0.0:
             assert rel(named[k].grad, w.reshape(named[k].shape)) < 1e-4, k
         else:
             assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0
