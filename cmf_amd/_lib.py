@@ -68,6 +68,7 @@ SIGNATURES = {
     "cmf_channel_sum": (_i, [_fp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _fp, _fp]),
     "cmf_grad_sqnorm": (_i, [_fp, _ll, _fp, _fp, _fp]),
     "cmf_optimizer_step": (_i, [_i, _fp, _fp, _fp, _fp, _ll, _d, _d, _d, _d, _d, _i, _fp, _f, _fp]),
+    "cmf_gram_backward_matrix": (_i, [_fp, _ll, _ll, _i, _i, _i, _i, _fp, _fp, _ll, _ll, _fp]),
     "cmf_gram_backward": (_i, [_fp, _ll, _ll, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _ll, _ll, _fp]),
     "cmf_prehead": (_i, [_fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _fp]),
     "cmf_prehead_inverse": (_i, [_fp, _fp, _f, _f, _i, _ll, _fp]),

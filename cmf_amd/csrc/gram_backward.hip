@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void gram_backward_kernel(const float* __restr
                                                             const float* __restrict__ g_logdet,
                                                             const float* __restrict__ g_l1off,
                                                             const float* __restrict__ g_l1diag, float* __restrict__ dt,
-                                                            long long dt_b, long long dt_r) {
+                                                            long long dt_b, long long dt_r, const float* __restrict__ m_in) {
   extern __shared__ __align__(16) float lds[];
   const int LD = nc + 4;                    // 16-byte aligned rows for the b128 reads of the product phase
   float* A = lds;                           // [d][LD]   G -> G^-1 -> M = 2 dG  (columns >= d stay 0)
@@ -33,6 +33,13 @@ __global__ __launch_bounds__(256) void gram_backward_kernel(const float* __restr
   const int ti = tid >> 4, tj = tid & 15;
   const float* G = jtj + (size_t)b * d * d;
 
+  if (m_in) {
+    // explicit cotangent of the Gram matrix (Hutchinson surrogate: M = mean_s u_s eps_s^T, not symmetric): dJ = J (M + M^T)
+    const float* M = m_in + (size_t)b * d * d;
+    for (int i = ti; i < d; i += 16)
+      for (int j = tj; j < LD; j += 16) A[i * LD + j] = j < d ? M[i * d + j] + M[j * d + i] : 0.f;
+    __syncthreads();
+  } else {
   for (int i = ti; i < d; i += 16)
     for (int j = tj; j < LD; j += 16) A[i * LD + j] = j < d ? G[i * d + j] : 0.f;
   __syncthreads();
@@ -68,6 +75,7 @@ __global__ __launch_bounds__(256) void gram_backward_kernel(const float* __restr
       A[i * LD + j] = 2.f * (ga * A[i * LD + j] + (i == j ? gd : go) * sg);
     }
   __syncthreads();
+  }
 
   // dJ = J M, SLAB rows at a time: thread (rg, q) owns columns 4q..4q+3 of rows rg, rg + rpp, ...
   const int nq = nc >> 2, rpp = 256 / nq;
@@ -106,7 +114,23 @@ extern "C" int cmf_gram_backward(const float* t, long long t_b, long long t_r, i
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(gram_backward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, t, t_b, t_r, n_rows, nc, d, jtj,
-                     g_logdet, g_l1off, g_l1diag, dt, dt_b, dt_r);
+                     g_logdet, g_l1off, g_l1diag, dt, dt_b, dt_r, (const float*)nullptr);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cmf_gram_backward_matrix(const float* t, long long t_b, long long t_r, int n_rows, int nc, int d, int B,
+                                        const float* m, float* dt, long long dt_b, long long dt_r, void* stream) {
+  if (!t || !m || !dt) return CMF_EINVAL;
+  if (n_rows <= 0 || B <= 0 || d <= 0 || d > nc || nc % 16 || nc > 128) return CMF_EINVAL;
+  if ((t_b | t_r | dt_b | dt_r) % 4 || (uintptr_t)t % 16 || (uintptr_t)dt % 16) return CMF_EINVAL;
+  const size_t lds = ((size_t)d * (nc + 4) + 2 * nc + (size_t)SLAB * nc) * sizeof(float);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)gram_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(gram_backward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, t, t_b, t_r, n_rows, nc, d, m,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dt, dt_b, dt_r, m);
   CMF_LAUNCH_CHECK();
   return 0;
 }

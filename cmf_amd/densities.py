@@ -756,18 +756,23 @@ class NonSquareHeadDensity(Density):
     # ------------------------------------------------------------------------------------------
     # training: forward with saved state, backward on the HIP kernels
     # ------------------------------------------------------------------------------------------
-    def head_terms_forward(self, z_low, tangents=True):
+    def head_terms_forward(self, z_low, tangents=True, hutch_eps=None):
         """Decode (with the Jacobian stack) keeping every layer's context, Gram + Cholesky; returns the state
-        ``head_terms_backward`` consumes."""
+        ``head_terms_backward`` consumes.  ``hutch_eps`` (B, d, S): also run the Hutchinson + CG surrogate of
+        non_square.py:203-258 on the explicit Gram matrix (train mode of ``log_jacobian_method = "hutch_with_cg"``)."""
         E.require_gpu(z_low)
         with torch.no_grad():
             x_hat, T, ctx = self.program.decode_train(z_low.detach(), tangents)
-            gr = None
+            gr = hutch = None
             if tangents:
                 gr = E.gram_cholesky(T, self.program.d)
                 if int(gr.fail[0].item()) != 0:
                     raise RuntimeError("J^T J is not positive definite at the first attempt: the jittered retries are not differentiated")
-        return {"x_hat": x_hat, "T": T, "ctx": ctx, "gram": gr}
+                if hutch_eps is not None:
+                    val, u, w, iters = E.hutch_cg(gr.jtj, hutch_eps, self.max_cg_iterations or self.program.d, self.cg_tolerance)
+                    hutch = {"eps": hutch_eps, "u": u, "w": w, "iterations": iters, "value": val}
+                    self.last_hutchinson = hutch
+        return {"x_hat": x_hat, "T": T, "ctx": ctx, "gram": gr, "hutch": hutch}
 
     def head_terms_backward(self, z_low, x, g_logdet=None, g_l1off=None, g_l1diag=None, g_rec=None, grads=None, state=None):
         """Parameter gradients and the latent cotangent of
@@ -781,7 +786,18 @@ class NonSquareHeadDensity(Density):
         x_hat, T, gr = st["x_hat"], st["T"], st["gram"]
         B = x_hat.shape[0]
         with torch.no_grad():
-            Ct = E.gram_backward(T, gr.jtj, g_logdet, g_l1off, g_l1diag) if tangents else None
+            Ct = None
+            if tangents and st.get("hutch") is not None:
+                # surrogate value_b = mean_s u_s^T (G eps_s) with u detached (the CG solve runs under no_grad in the reference,
+                # non_square.py:236-247): d value / d G = mean_s u_s eps_s^T, handed over as an explicit matrix
+                if g_l1off is not None or g_l1diag is not None:
+                    raise NotImplementedError("g-term on the (B, d, S) Hutchinson product is not built")
+                h = st["hutch"]
+                S = h["eps"].shape[2]
+                M = torch.einsum("bis,bjs->bij", h["u"], h["eps"]) * (g_logdet.to(torch.float32) / S).view(B, 1, 1)
+                Ct = E.gram_backward_matrix(T, M)
+            elif tangents:
+                Ct = E.gram_backward(T, gr.jtj, g_logdet, g_l1off, g_l1diag)
             dx = torch.zeros_like(x_hat)
             if g_rec is not None:
                 dx = 2.0 * g_rec.to(torch.float32).view(B, *([1] * (x_hat.dim() - 1))) * (x_hat - x)
@@ -789,6 +805,8 @@ class NonSquareHeadDensity(Density):
         out = {"x_hat": x_hat, "dz_low": dz, "grads": grads}
         if gr is not None:
             out.update(logdet=gr.logdet, l1_off=gr.l1_off, l1_diag=gr.l1_diag)
+        if st.get("hutch") is not None:
+            out["logdet"] = st["hutch"]["value"]
         return out
 
     def train_forward(self, x, add_reconstruction=True, add_diagonal_metric_reg=False, add_offdiagonal_metric_reg=False,
@@ -797,21 +815,28 @@ class NonSquareHeadDensity(Density):
         ``train_backward`` needs (every layer's input, activations, input tangents: ~17 hidden tangent tensors per ResNet
         coupler stay alive -- 131 GB for MNIST d = 64 at the reference's 64 samples per GPU).  ``x`` = the head's input."""
         E.require_gpu(x)
-        if self._jacobian_free or (self.training and self.log_jacobian_method != "cholesky"):
-            raise NotImplementedError("training gradients are built for the exact (cholesky) log-det path")
+        if self._jacobian_free:
+            raise NotImplementedError("training gradients of the M-flow baseline head are not built")
         assert not (add_diagonal_metric_reg and add_offdiagonal_metric_reg)
         prog, B, dev = self.program, x.shape[0], x.device
         want_lik = not np.isclose(likelihood_wt, 0.)
+        hutch = want_lik and self.training and self.log_jacobian_method == "hutch_with_cg"     # non_square.py:131-138
+        if hutch and (add_diagonal_metric_reg or add_offdiagonal_metric_reg):
+            if self.num_hutchinson_samples != prog.d:
+                raise ValueError("metric regularisation with hutch_with_cg needs num_hutchinson_samples == "
+                                 "latent_dimension (the reference fails at non_square.py:98 otherwise)")
+            raise NotImplementedError("g-term on the (B, d, S) Hutchinson product is not built")
         with torch.no_grad():
             x = x.contiguous()
             z_low, low_elbo, u, ctx, pctx = prog.encode_train(x)
-            head = self.head_terms_forward(z_low, tangents=want_lik)
+            head = self.head_terms_forward(z_low, tangents=want_lik, hutch_eps=self._hutchinson_probes(B, dev) if hutch else None)
             gr = head["gram"]
             rec = E.recon_sqerr(head["x_hat"], x) if add_reconstruction else None
-            l1 = None
+            l1 = logdet = None
             if want_lik:
                 l1 = gr.l1_diag if add_diagonal_metric_reg else (gr.l1_off if add_offdiagonal_metric_reg else None)
-            elbo = E.elbo_combine(low_elbo if want_lik else None, gr.logdet if want_lik else None, rec, l1, pre_logjac,
+                logdet = head["hutch"]["value"] if hutch else gr.logdet
+            elbo = E.elbo_combine(low_elbo if want_lik else None, logdet, rec, l1, pre_logjac,
                                   likelihood_wt, self.regularization_param, metric_wt, B, dev)
         state = dict(x=x, z_low=z_low, u=u, ctx=ctx, pctx=pctx, head=head, want_lik=want_lik, rec=add_reconstruction,
                      diag=add_diagonal_metric_reg, off=add_offdiagonal_metric_reg, wl=float(likelihood_wt), wm=float(metric_wt))

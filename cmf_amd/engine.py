@@ -424,6 +424,16 @@ def gram_backward(T, jtj, g_logdet=None, g_l1off=None, g_l1diag=None):
     return dT
 
 
+def gram_backward_matrix(T, M):
+    """dT = T (M + M^T) for an explicit cotangent M (B, d, d) of the Gram matrix (Hutchinson surrogate training)."""
+    B, d = M.shape[0], M.shape[1]
+    assert B == T.B and d <= T.nc
+    dT = T.like(T.N)
+    _lib.check(_lib.load().cmf_gram_backward_matrix(_p(T.data), T.t_b, T.t_r, T.N, T.nc, d, B, _p(M.to(torch.float32).contiguous()),
+                                                    _p(dT.data), dT.t_b, dT.t_r, _stream()), "cmf_gram_backward_matrix")
+    return dT
+
+
 def hutch_cg(jtj, eps, max_iter, tol, min_iter=None):
     """Hutchinson surrogate on explicit J^T J: returns (value (B,), u, w (B,d,S), iterations (B,))."""
     B, d, S = eps.shape

@@ -222,6 +222,10 @@ int cmf_cholesky_retry(float* jtj, int d, int B, int attempt, float eps0, float*
 int cmf_gram_backward(const float* t, long long t_b, long long t_r, int n_rows, int nc, int d, int B,
                       const float* jtj, const float* g_logdet, const float* g_l1off, const float* g_l1diag,
                       float* dt, long long dt_b, long long dt_r, void* stream);
+/* The same product for an EXPLICIT cotangent m [B][d][d] of the Gram matrix (not necessarily symmetric):
+ * dt = t (m + m^T).  Training on the Hutchinson surrogate (non_square.py:203-258): m = mean_s u_s eps_s^T, u detached.   */
+int cmf_gram_backward_matrix(const float* t, long long t_b, long long t_r, int n_rows, int nc, int d, int B,
+                             const float* m, float* dt, long long dt_b, long long dt_r, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small per-sample reductions / elementwise maps.                                                 */
