@@ -65,6 +65,8 @@ SIGNATURES = {
     "cmf_cholesky_retry": (_i, [_fp, _i, _i, _i, _f, _fp, _fp, _fp, _fp, _fp]),
     "cmf_stanh_backward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
     "cmf_tanh_cross_terms": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _fp, _fp, _i, _i, _i, _fp]),
+    "cmf_accumulate": (_i, [_fp, _fp, _ll, _fp]),
+    "cmf_relu_bits": (_i, [_fp, _fp, _i, _i, _i, _fp]),
     "cmf_channel_sum": (_i, [_fp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _fp, _fp]),
     "cmf_grad_sqnorm": (_i, [_fp, _ll, _fp, _fp, _fp]),
     "cmf_optimizer_step": (_i, [_i, _fp, _fp, _fp, _fp, _ll, _d, _d, _d, _d, _d, _i, _fp, _f, _fp]),

@@ -107,7 +107,11 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // input's own relu, no factor stream).  Compile-time: every loader VALU instruction delays the MFMA wave it shares
   // a SIMD with.
   constexpr bool SELF = MODE == 2, RELU = MODE == 1, BITS = MODE == 3;   // 3 = relu' from a bit mask (CMF_F_RELU_BITS)
-  constexpr int NF = SELF ? 0 : BITS ? 1 : 8;                    // factor loads per loader thread and chunk
+  // 4 = PLAIN: no input factor at all (no factor stream, like SELF, and no relu) and an optional OUTPUT-side relu' bit mask
+  // applied at the store -- the reverse (cotangent) sweep: the adjoint of "mask, then conv" is "transposed conv, then mask"
+  constexpr bool PLAIN = MODE == 4;
+  constexpr bool NOF = SELF || PLAIN;                            // no factor stream
+  constexpr int NF = NOF ? 0 : BITS ? 1 : 8;                     // factor loads per loader thread and chunk
   using C = BCfg<COT, PXW>;
   constexpr int CW = COT / 2, PW = C::PW;
   static_assert(COT % 2 == 0, "the co-split wave layout needs an even number of output-channel tiles");
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     const float fc1 = (a.fmode == CMF_F_RELU) ? 1.f : 0.f;
     const float fc2 = (a.fmode == CMF_F_RAW) ? 1.f : 0.f;
     const float fc3 = (a.fmode == CMF_F_TANH) ? -1.f : 0.f;
-    constexpr bool has_f = !SELF;                                // compile-time: the wait counts below depend on it
+    constexpr bool has_f = !NOF;                                 // compile-time: the wait counts below depend on it
                                                                  // (the launcher rejects fmode NONE without SELF)
     const int fgrp = a.f_group > 1 ? a.f_group : 1;
 
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float f = r.f[j];
-          const float m = SELF ? r.okf : BITS ? (((__builtin_bit_cast(unsigned, r.f[0]) >> j) & 1u) ? r.okf : 0.f)
+          const float m = NOF ? r.okf : BITS ? (((__builtin_bit_cast(unsigned, r.f[0]) >> j) & 1u) ? r.okf : 0.f)
                                : RELU ? (f > 0.f ? r.okf : 0.f)
                                               : r.okf * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
 #pragma unroll
@@ -504,6 +508,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   const int rvoff = 4 * ((cohalf * CW * 16 + cl) * r_co + kq * 4);
   struct Item {
     int ypix, rpix;                                                // byte offset of pixel p = 0 of this wave's tile row
+    int pix0, np, cog;                                             // (PLAIN) pixel index of p = 0, sample, channel group: output mask
   };
   auto item_geom = [&](int item, int& np, int& slice, int& cog, Item& it) {
     int tile;
@@ -511,6 +516,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     const int pix0 = (C::TH * (tile / tiles_x) + wrow) * a.W + C::TW * (tile % tiles_x);
     it.ypix = 4 * pix0 * y_px;
     it.rpix = 4 * pix0 * r_px;
+    it.pix0 = pix0, it.np = np, it.cog = cog;
   };
   // descriptors are built from readfirstlane'd words: hipcc otherwise keeps loop-carried descriptors in VGPRs and
   // wraps every access in a waterfall loop
@@ -574,10 +580,39 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(acc[p][c]) : "v"(rvoff), "s"(rrs), "s"(so) : "memory");
     }
   };
+  // PLAIN: relu' bits of this wave's 32 output channels, one dword per pixel (CMF_F_RELU_BITS layout: cout / 8 bytes per
+  // pixel), fetched with SCALAR loads (lgkmcnt, not the hand-counted vmcnt) at the top of the item's last chunk.  One asm
+  // statement per load WITH its wait: an s_load writes its SGPR asynchronously, and a destination the compiler believed
+  // defined could be spilled, moved or reused before the data arrived.  The address is always valid and the fetch is
+  // unconditional (the launcher points a missing mask at the input tensor and clears fomode): no divergent paths here.
+  unsigned omask[PW];
+  const bool use_omask = PLAIN && a.fomode == CMF_F_RELU_BITS;
+  auto load_omask = [&](const Item& it) __attribute__((always_inline)) {
+    if constexpr (PLAIN) {
+      const unsigned long long base = reinterpret_cast<unsigned long long>(a.fo) + (unsigned long long)it.np * a.fo_np +
+                                      (unsigned)(it.cog * 8 + cohalf * 4);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+      const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+      const int stride = a.cout / 8;
+#pragma unroll
+      for (int p = 0; p < PW; ++p) {
+        const int off = __builtin_amdgcn_readfirstlane((it.pix0 + (p / C::TW) * a.W + p % C::TW) * stride);
+        unsigned w;
+        asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w) : "s"(sb), "s"(off) : "memory");
+        omask[p] = use_omask ? w : ~0u;
+      }
+    }
+  };
   auto store_pixel = [&](const Item& it, int p) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-      const f32x4 v = acc[p][c] + bias[c];                         // per-channel constant (primal bias)
+      f32x4 v = acc[p][c];
+      if constexpr (PLAIN) {
+        const bool on = (omask[p] >> (c * 16 + cl)) & 1u;
+        v = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      v += bias[c];                                                // per-channel constant (primal bias)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, v), cur_yrs, yvoff,
                                              it.ypix + 4 * (((p / C::TW) * a.W + p % C::TW) * y_px + c * 16 * y_co), 0);
     }
@@ -612,6 +647,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     return;
 #endif
     constexpr int KS = QUAD ? 3 : 2, NSTEP = KS * PW;              // step t = KS*p + s (pixel-major)
+    if (LAST) load_omask(cur);                                     // PLAIN only: scalar loads, land during this chunk
     const unsigned char* Xh = smem + stage * C::BUF_BYTES;
     const unsigned char* Xl = Xh + C::XS_BYTES;
     const unsigned char* Wh = Xh + 2 * C::XS_BYTES;
@@ -805,6 +841,7 @@ int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
   if (a.fmode == CMF_F_SELF_RELU) return (a.cout > 32) ? launch<4, PXW, 2>(a, s) : launch<2, PXW, 2>(a, s);
   if (a.fmode == CMF_F_RELU) return (a.cout > 32) ? launch<4, PXW, 1>(a, s) : launch<2, PXW, 1>(a, s);
   if (a.fmode == CMF_F_RELU_BITS) return (a.cout > 32) ? launch<4, PXW, 3>(a, s) : launch<2, PXW, 3>(a, s);
+  if (a.fmode == CMF_F_NONE) return (a.cout > 32) ? launch<4, PXW, 4>(a, s) : launch<2, PXW, 4>(a, s);
   return (a.cout > 32) ? launch<4, PXW, 0>(a, s) : launch<2, PXW, 0>(a, s);
 }
 
@@ -829,10 +866,15 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   const cmf_conv_tangent_args& a = *ap;
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
   if (a.taps != 9 || a.cin % 32 || a.nc <= 0 || a.nc % 16) return CMF_EINVAL;   // K packing works on groups of 4 octets
-  if (a.fmode <= CMF_F_NONE || a.fmode > CMF_F_RELU_BITS) return CMF_EINVAL;   // NONE: use cmf_conv_tangent (the loader's
-                                                                              // load schedule always carries a factor stream)
-  if (a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
-  if (a.fo || a.mask_out) return CMF_EINVAL;                    // output-side factors / sign-bit output: cmf_conv_tangent only
+  if (a.fmode < CMF_F_NONE || a.fmode > CMF_F_RELU_BITS) return CMF_EINVAL;
+  if (a.fmode != CMF_F_SELF_RELU && a.fmode != CMF_F_NONE && !a.f) return CMF_EINVAL;
+  if (a.mask_out) return CMF_EINVAL;                            // sign-bit output: cmf_conv_tangent only
+  if (a.fo) {
+    // output-side factor: only as a relu' BIT MASK, without input factor and without residual (the residual is the
+    // accumulators' initial value and would be masked with the product), whole groups of 64 output channels
+    if (a.fmode != CMF_F_NONE || a.fomode != CMF_F_RELU_BITS || a.r || a.cout % 64) return CMF_EINVAL;
+    if (a.fo_np % 4 || (uintptr_t)a.fo % 4 || a.fo_np < (long long)a.H * a.W * (a.cout / 8)) return CMF_EINVAL;
+  }
   if (a.fmode == CMF_F_RELU_BITS && a.f_np < (long long)a.H * a.W * (a.cin / 8)) return CMF_EINVAL;
   if ((a.x_np | a.x_ci | a.x_px | a.x_sl | a.y_sl | a.r_sl) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
   if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;            // 16-byte stores
@@ -848,5 +890,14 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   const bool t14 = a.W % 14 == 0 && a.H % 2 == 0, t8 = a.W % 8 == 0 && a.H % 4 == 0;
   if (!(t14 || t8) || !(a.cout % 64 == 0 || a.cout == 32)) return CMF_EINVAL;
   if (a.bias && a.cout > 64) return CMF_EINVAL;                 // the per-channel constants are fetched once per launch
+  if (a.fmode == CMF_F_NONE && !a.fo) {
+    // the PLAIN kernel fetches its output mask unconditionally: without one, let it read (and ignore) the first bytes of
+    // every sample's input tensor -- H*W*cout/8 bytes per sample, always inside x (cin*nc*4 >= 2 KiB per pixel)
+    cmf_conv_tangent_args b = a;
+    b.fo = a.x;
+    b.fo_np = 0;
+    b.fomode = CMF_F_NONE;
+    return t14 ? launch_cot<7>(b, s) : launch_cot<4>(b, s);
+  }
   return t14 ? launch_cot<7>(a, s) : launch_cot<4>(a, s);
 }

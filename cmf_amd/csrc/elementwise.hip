@@ -133,6 +133,17 @@ __global__ void acl_primal_backward_kernel(float* __restrict__ dx, long long dx_
   }
 }
 
+// dst += src over n floats (n % 4 == 0): the skip connection of the reverse sweep, c_h = c_h2 + relu'(a) . conv1^T(c_u), when the
+// masked product comes from the split-precision kernel (whose residual input would be masked with the product)
+__global__ void accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4) {
+  const long long stride = (long long)gridDim.x * TPB;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += stride) {
+    f32x4 d = reinterpret_cast<f32x4*>(dst)[i];
+    d += reinterpret_cast<const f32x4*>(src)[i];
+    reinterpret_cast<f32x4*>(dst)[i] = d;
+  }
+}
+
 // acl cross terms (training): the tangent update  out = es (v - zo gs sd) - gt td  also depends on PRIMAL quantities;
 // their cotangents are column reductions of c . d(out)/d(.) -- one wavefront per (sample, modified element):
 //   d s  = -sum_col c es (v - zo gs sd)     d zo = -sum_col c es gs sd
@@ -398,6 +409,15 @@ int cmf_acl_primal_backward(float* dx, long long dx_b, const float* z, long long
   const long long total = (long long)B * n_mod;
   hipLaunchKernelGGL(acl_primal_backward_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, dx, dx_b, z, z_b, y, y_b,
                      dy, zi, si, ti, n_mod, total, decode, dlj);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+int cmf_accumulate(float* dst, const float* src, long long n, void* stream) {
+  if (!dst || !src || n <= 0 || n % 4 || ((uintptr_t)dst | (uintptr_t)src) % 16) return CMF_EINVAL;
+  const long long n4 = n / 4;
+  const int blocks = (int)(n4 / TPB + 1 < 16384 ? n4 / TPB + 1 : 16384);
+  hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(TPB), 0, (hipStream_t)stream, dst, src, n4);
   CMF_LAUNCH_CHECK();
   return 0;
 }

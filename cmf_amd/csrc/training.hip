@@ -79,6 +79,25 @@ __global__ __launch_bounds__(256) void tanh_cross_terms_kernel(float* __restrict
   if (lane == 0) dh[b * F + f] += -2.f * hv * acc;
 }
 
+// relu' bit mask of an activation tensor (B, C, HW) in the CMF_F_RELU_BITS layout [B][HW][C / 8]: bit j of a byte = [act > 0]
+// of channel 8 * octet + j.  (The eval path gets these bits from the primal conv's epilogue; training keeps float activations
+// for the weight gradients and derives the bits for the split-precision transposed convs here.)
+__global__ __launch_bounds__(256) void relu_bits_kernel(const float* __restrict__ act, unsigned char* __restrict__ out, int C, int HW,
+                                                        long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int noct = C / 8;
+  const int px = (int)(i % HW);
+  const long long r = i / HW;
+  const int oct = (int)(r % noct);
+  const long long b = r / noct;
+  const float* p = act + (b * C + oct * 8) * (long long)HW + px;
+  unsigned bits = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bits |= (p[(long long)j * HW] > 0.f ? 1u : 0u) << j;
+  out[(b * HW + px) * noct + oct] = (unsigned char)bits;
+}
+
 }  // namespace
 
 extern "C" int cmf_stanh_backward(const float* dy, const float* dg, const float* y, const float* g, const float* sw,
@@ -105,6 +124,15 @@ extern "C" int cmf_tanh_cross_terms(float* c, long long c_b, long long c_r, cons
   const long long n_rows = (long long)B * F;
   hipLaunchKernelGGL(tanh_cross_terms_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, c, c_b, c_r, x,
                      x_b, x_r, h, dh, F, nc, n_rows);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cmf_relu_bits(const float* act, void* out, int B, int C, int HW, void* stream) {
+  if (!act || !out || B <= 0 || C <= 0 || C % 8 || HW <= 0) return CMF_EINVAL;
+  const long long total = (long long)B * (C / 8) * HW;
+  hipLaunchKernelGGL(relu_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, act,
+                     (unsigned char*)out, C, HW, total);
   CMF_LAUNCH_CHECK();
   return 0;
 }

@@ -101,7 +101,7 @@ def _use_bf16x3(taps, cin, W, transpose, H=None, cout=64):
 def _shape_ok_bf16x3(taps, cin, W, transpose, H=None, cout=64):
     """Shapes the split-precision kernel is built for: whole 2 x 14 (or 2 x 8) pixel tiles, whole 64- (or one 32-) channel groups."""
     return (taps == 9 and cin % 8 == 0 and cin % 32 == 0 and ((W % 14 == 0 and (H is None or H % 2 == 0)) or (W % 8 == 0 and (H is None or H % 4 == 0)))
-            and (cout % 64 == 0 or cout == 32) and not transpose)
+            and (cout % 64 == 0 or cout == 32))
 
 
 class Tangent:
@@ -168,6 +168,9 @@ class _PackCache:
         n = C.c_longlong(0)
         w = weight.detach().contiguous()
         if bf16x3:
+            if transpose:                                  # the adjoint operator: channels swapped, taps flipped (tiny, once per version)
+                w = w.transpose(0, 1).flip(2, 3).contiguous()
+                cout, cin = cin, cout
             _lib.check(lib.cmf_pack_weight_bf16x3(None, None, cout, cin, C.byref(n), None), "pack size")
             out = torch.empty(n.value, dtype=torch.uint8, device=weight.device)
             _lib.check(lib.cmf_pack_weight_bf16x3(_p(w), _p(out), cout, cin, None, _stream()), "cmf_pack_weight_bf16x3")
@@ -215,8 +218,14 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     a = ConvTangentArgs()
     a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
     a.f = _p(f); a.f_np, a.f_ci, a.f_px = int(f_np), int(f_ci), int(f_px); a.fmode = fmode
+    # split-precision kernel: any input factor without output factor, or NO input factor with an optional relu' BIT MASK on the
+    # output (no residual then): the transposed convs of the reverse sweep
+    obits = isinstance(fo, BitMask)
     split = ((precision or TANGENT_PRECISION) == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
-             and fmode != F_NONE and fo is None)          # the split kernel always streams a factor; no output factor
+             and ((fmode != F_NONE and fo is None) or (fmode == F_NONE and (fo is None or (obits and res_t is None and cout % 64 == 0)))))
+    assert not obits or split, "bit-mask output factors are applied by the split-precision kernel only"
+    if obits:
+        fo, fo_np, fo_co, fo_px, fomode = fo.data, fo.np_bytes, 0, 0, F_RELU_BITS
     a.w = _p(PACKS.get(weight, taps, transpose, bf16x3=split))
     a.y = C.c_void_p(y_t.data_ptr() + 4 * int(y_off)); a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
     a.r = None if res_t is None else C.c_void_p(res_t.data_ptr() + 4 * int(res_off))
@@ -363,6 +372,20 @@ def acl_cross_terms(Ct, V, YT, z, y, g, maps, dz, dy, dg):
                                                Ct.nc, _p(z2), z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]),
                                                _p(maps["si"]), _p(maps["ti"]), maps["n"], B, _p(dz), _p(dy), _p(dg), _stream()),
                "cmf_acl_cross_terms")
+
+
+def relu_bits(act):
+    """BitMask of [act > 0] for an activation tensor (B, C, H, W) (CMF_F_RELU_BITS layout)."""
+    B, Cc = act.shape[0], act.shape[1]
+    HW = act[0, 0].numel()
+    m = BitMask(B, HW, Cc, act.device)
+    _lib.check(_lib.load().cmf_relu_bits(_p(act.contiguous()), _p(m.data), B, Cc, HW, _stream()), "cmf_relu_bits")
+    return m
+
+
+def accumulate(dst, src):
+    """dst += src (flat fp32 tensors of equal size)."""
+    _lib.check(_lib.load().cmf_accumulate(_p(dst), _p(src), min(dst.numel(), src.numel()), _stream()), "cmf_accumulate")
 
 
 def stanh_backward(dy, dg, y, g, sw, sb, dsw=None, dsb=None):
@@ -732,6 +755,11 @@ def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None, cross=None):
         hd, hsl = (hid * HW * nc, 16, hid * nc), hid * 16  # the forward pass's slice-major hidden layout (net_tangent)
         fa = dict(fo_np=hid * HW, fo_co=HW, fo_px=1, fomode=F_RELU)
         fr = dict(fmode=F_RELU, f_np=hid * HW, f_ci=HW, f_px=1)
+        # The hidden 3x3 transposed convs run on the split-precision kernel when the forward ones do: no input factor, relu' as
+        # an output BIT MASK (derived from the float activations), cotangents slice-major like the forward tangents; the skip
+        # connection is a separate accumulate (the kernel's residual input would be masked with the product).
+        split = TANGENT_PRECISION == "bf16x3" and _shape_ok_bf16x3(9, hid, W, True, H, hid) and hid % 64 == 0
+        cd, csl = (hd, hsl) if split else (pn(hid), 16)    # layout of the hidden cotangents
         if train:
             t_in, hs, us = saved[0], saved[1::2], saved[2::2]  # h_0 .. h_K, u_0 .. u_{K-1}
             assert len(hs) == len(blocks) + 1 and len(us) == len(blocks)
@@ -740,31 +768,40 @@ def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None, cross=None):
                                f=acts[-1], x_sl=hsl, **fr)
         # y = convf(relu'(a_last) . h)  ->  c_h = relu'(a_last) . convf^T(c_y)
         ch = new(hid)
-        conv_tangent(YC.data, 0, *pn(cout), convf.weight, 1, ch.data, *pn(hid), B, cout, hid, H, W, nc, fo=acts[-1], **fa, **f32)
+        conv_tangent(YC.data, 0, *pn(cout), convf.weight, 1, ch.data, *cd, B, cout, hid, H, W, nc, fo=acts[-1], y_sl=csl, **fa, **f32)
         u, ch2 = new(hid), new(hid)
         for k in reversed(range(len(blocks))):
             blk, a_in, c1 = blocks[k], acts[2 * k], acts[2 * k + 1]
             # h2 = h + conv2(relu'(c1) . u), u = conv1(relu'(a_in) . h):
             #   c_u = relu'(c1) . conv2^T(c_h2);   c_h = c_h2 + relu'(a_in) . conv1^T(c_u)
             if train:
-                conv_tangent_wgrad(us[k].data, 0, *hd, ch.data, 0, *pn(hid), _grad_of(grads, blk.conv2.weight), 9, B, hid, hid, H, W,
-                                   nc, f=c1, x_sl=hsl, **fr)
-            conv_tangent(ch.data, 0, *pn(hid), blk.conv2.weight, 9, u.data, *pn(hid), B, hid, hid, H, W, nc, fo=c1, **fa, **f32)
+                conv_tangent_wgrad(us[k].data, 0, *hd, ch.data, 0, *cd, _grad_of(grads, blk.conv2.weight), 9, B, hid, hid, H, W,
+                                   nc, f=c1, x_sl=hsl, y_sl=csl, **fr)
+            if split:
+                conv_tangent(ch.data, 0, *cd, blk.conv2.weight, 9, u.data, *cd, B, hid, hid, H, W, nc, fo=relu_bits(c1),
+                             transpose=True, x_sl=csl, y_sl=csl)
+            else:
+                conv_tangent(ch.data, 0, *cd, blk.conv2.weight, 9, u.data, *cd, B, hid, hid, H, W, nc, fo=c1, **fa, **f32)
             if train:
-                conv_tangent_wgrad(hs[k].data, 0, *hd, u.data, 0, *pn(hid), _grad_of(grads, blk.conv1.weight), 9, B, hid, hid, H, W,
-                                   nc, f=a_in, x_sl=hsl, **fr)
-            conv_tangent(u.data, 0, *pn(hid), blk.conv1.weight, 9, ch2.data, *pn(hid), B, hid, hid, H, W, nc, res_t=ch.data,
-                         fo=a_in, **fa, **f32)
+                conv_tangent_wgrad(hs[k].data, 0, *hd, u.data, 0, *cd, _grad_of(grads, blk.conv1.weight), 9, B, hid, hid, H, W,
+                                   nc, f=a_in, x_sl=hsl, y_sl=csl, **fr)
+            if split:
+                conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch2.data, *cd, B, hid, hid, H, W, nc, fo=relu_bits(a_in),
+                             transpose=True, x_sl=csl, y_sl=csl)
+                accumulate(ch2.data, ch.data)
+            else:
+                conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch2.data, *cd, B, hid, hid, H, W, nc, res_t=ch.data,
+                             fo=a_in, **fa, **f32)
             ch, ch2 = ch2, ch
         # h0 = conv0(mask . v_in)  ->  Ct[view] += mask . conv0^T(c_h0)
         off = view.chan_off * HW * nc
         m = view.mask
         if train:
-            conv_tangent_wgrad(t_in.data, 0, *pn(view.cin), ch.data, 0, *pn(hid), _grad_of(grads, conv0.weight), 9, B, view.cin, hid,
-                               H, W, nc, fmode=F_RAW if m is not None else F_NONE, f=m, f_np=0, f_ci=HW, f_px=1)
-        conv_tangent(ch.data, 0, *pn(hid), conv0.weight, 9, Ct.data, Ct.t_b, view.chan_step * HW * nc, nc, B, hid, view.cin, H, W, nc,
+            conv_tangent_wgrad(t_in.data, 0, *pn(view.cin), ch.data, 0, *cd, _grad_of(grads, conv0.weight), 9, B, view.cin, hid,
+                               H, W, nc, fmode=F_RAW if m is not None else F_NONE, f=m, f_np=0, f_ci=HW, f_px=1, y_sl=csl)
+        conv_tangent(ch.data, 0, *cd, conv0.weight, 9, Ct.data, Ct.t_b, view.chan_step * HW * nc, nc, B, hid, view.cin, H, W, nc,
                      y_off=off, res_t=Ct.data, res_off=off, fo=m, fo_np=0, fo_co=HW, fo_px=1,
-                     fomode=F_RAW if m is not None else F_NONE, **f32)
+                     fomode=F_RAW if m is not None else F_NONE, x_sl=csl, **f32)
         return
     lins = [mod for mod in net if isinstance(mod, nn.Linear)]
     # x_i = W_i (phi_{i-1} . x_{i-1}), phi_0 = 1, phi_i = tanh'(h_i):  c_{i-1} = phi_{i-1} . W_i^T c_i  (output-side factor);

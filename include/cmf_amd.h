@@ -101,8 +101,10 @@ int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
  * cout % 64 == 0 or cout == 32 (anything else: CMF_EINVAL, use cmf_conv_tangent): operands are split
  * v = hi + lo (bf16 each) and multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
  * accumulation (fp32-grade result, ~2^-16 relative per product).  `w` must come from
- * cmf_pack_weight_bf16x3 (out == NULL: size query in bytes through *out_bytes).  fmode CMF_F_NONE is
- * rejected (CMF_EINVAL): this kernel's load schedule always carries a factor stream; use cmf_conv_tangent. */
+ * cmf_pack_weight_bf16x3 (out == NULL: size query in bytes through *out_bytes).  Output-side factor: only with
+ * fmode CMF_F_NONE, no residual, cout % 64 == 0 and fomode CMF_F_RELU_BITS -- fo is then a relu' bit mask over the OUTPUT
+ * channels (byte np*fo_np + px*(cout/8) + co/8, fo_np in bytes; written by cmf_relu_bits or mask_out): the transposed convs of
+ * the reverse sweep.  mask_out is not supported. */
 int cmf_pack_weight_bf16x3(const float* w, void* out, int cout, int cin, long long* out_bytes, void* stream);
 int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* a, void* stream);
 
@@ -268,6 +270,11 @@ int cmf_stanh_backward(const float* dy, const float* dg, const float* y, const f
  *     c <- phi c  (in place: the cotangent of layer i's raw output);   dh[b][f] += -2 h sum_col c_old x                    */
 int cmf_tanh_cross_terms(float* c, long long c_b, long long c_r, const float* x, long long x_b, long long x_r,
                          const float* h, float* dh, int F, int B, int nc, void* stream);
+/* dst[i] += src[i], n % 4 == 0, 16-byte aligned: the skip connection of the reverse sweep next to the split-precision kernel. */
+int cmf_accumulate(float* dst, const float* src, long long n, void* stream);
+/* relu' bit mask of an activation tensor act (B, C, HW), C % 8 == 0, in the CMF_F_RELU_BITS layout: out[B][HW][C/8] bytes,
+ * bit j of byte (b, px, o) = [act(b, 8 o + j, px) > 0].                                                                  */
+int cmf_relu_bits(const float* act, void* out, int B, int C, int HW, void* stream);
 /* out[c] += sum_{n, px, col} t(n, c, px, col) over a tangent-layout tensor (element at n*t_np + c*t_c + px*t_px +
  * (col/16)*t_sl + col%16, t_sl = 0 meaning 16): the bias gradient of nn.Conv2d / nn.Linear.                        */
 int cmf_channel_sum(const float* t, long long t_np, long long t_c, long long t_px, long long t_sl, int np, int C,

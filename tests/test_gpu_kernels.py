@@ -24,8 +24,8 @@ def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, monke
     [sample][pixel][16-column slice][channel][16] addressed through x_sl / y_sl (include/cmf_amd.h)."""
     from cmf_amd import engine as E
     monkeypatch.setattr(E, "TANGENT_PRECISION", precision)
-    if precision == "bf16x3" and (not E._use_bf16x3(taps, cin, W, False, H, cout) or fmode == "none"):
-        pytest.skip("shape / mode not covered by the split-precision kernel (the engine falls back to fp32)")
+    if precision == "bf16x3" and not E._use_bf16x3(taps, cin, W, False, H, cout):
+        pytest.skip("shape not covered by the split-precision kernel (the engine falls back to fp32)")
     if layout == "slice" and (cin, cout, H) not in ((64, 64, 14), (64, 64, 28), (64, 64, 32), (2, 64, 14), (64, 4, 14), (16, 40, 5),
                                                    (32, 64, 14), (64, 32, 14), (128, 64, 14), (96, 128, 6)):
         pytest.skip("slice-major layout: a subset of the shapes is enough")
@@ -313,3 +313,42 @@ def test_channel_sum(layout):
         dev = t.reshape(B, Cc, HW, nc // 16, 16).permute(0, 2, 3, 1, 4).contiguous().cuda()
         E.channel_sum(dev, Cc * HW * nc, 16, Cc * nc, B, Cc, HW, nc, out, t_sl=Cc * 16)
     assert rel(out - 2, t.double().sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("H,W,cl_out,cl_in", [(14, 14, 64, 64), (28, 28, 64, 64), (8, 16, 64, 128), (6, 14, 128, 64)])
+@pytest.mark.parametrize("layout", ["panel", "slice"])
+def test_transposed_conv_with_output_bit_mask_on_the_split_kernel(H, W, cl_out, cl_in, layout, monkeypatch):
+    """Reverse-sweep conv on the split-precision kernel: transposed / tap-flipped bf16x3 pack, NO input factor, relu' of a
+    float activation as an OUTPUT bit mask (cmf_relu_bits), then the skip connection through cmf_accumulate:
+    y = skip + [act > 0] . conv^T(x)   against conv_transpose2d."""
+    from cmf_amd import engine as E
+    monkeypatch.setattr(E, "TANGENT_PRECISION", "bf16x3")
+    gen = torch.Generator().manual_seed(H * W + cl_in)
+    B, nc, HW = 2, 32, H * W
+    w = torch.randn(cl_out, cl_in, 3, 3, generator=gen) / (9 * cl_out) ** 0.5        # the LAYER's weight: cl_in -> cl_out
+    x = torch.randn(B, cl_out, H, W, nc, generator=gen)                               # cotangent of the layer's output
+    act = torch.randn(B, cl_in, H, W, generator=gen)
+    skip = torch.randn(B, cl_in, H, W, nc, generator=gen)
+    xin = x.permute(0, 4, 1, 2, 3).reshape(B * nc, cl_out, H, W)
+    want = F.conv_transpose2d(xin, w, padding=1).reshape(B, nc, cl_in, H, W).permute(0, 2, 3, 4, 1)
+    want = skip + (act > 0).float().unsqueeze(-1) * want
+    if layout == "panel":
+        to_dev = lambda t: t.contiguous().cuda()
+        from_dev = lambda t, c: t
+        st = lambda c: (c * HW * nc, HW * nc, nc)
+        sl = lambda c: 16
+    else:
+        S = nc // 16
+        to_dev = lambda t: t.reshape(B, -1, HW, S, 16).permute(0, 2, 3, 1, 4).contiguous().cuda()
+        from_dev = lambda t, c: t.reshape(B, HW, S, c, 16).permute(0, 3, 1, 2, 4).reshape(B, c, H, W, nc)
+        st = lambda c: (c * HW * nc, 16, c * nc)
+        sl = lambda c: c * 16
+    bits = E.relu_bits(act.cuda())
+    ref_bits = ((act > 0).permute(0, 2, 3, 1).reshape(B, HW, cl_in // 8, 8).int() * (1 << torch.arange(8)).int()).sum(-1)
+    assert torch.equal(bits.data.cpu().int(), ref_bits)
+    y = torch.full((B * cl_in * HW * nc,), float("nan"), device="cuda")
+    wd = torch.nn.Parameter(w.cuda())
+    E.conv_tangent(to_dev(x), 0, *st(cl_out), wd, 9, y, *st(cl_in), B, cl_out, cl_in, H, W, nc, fo=bits, transpose=True,
+                   x_sl=sl(cl_out), y_sl=sl(cl_in))
+    E.accumulate(y, to_dev(skip).reshape(-1))
+    assert rel(from_dev(y, cl_in).reshape(B, cl_in, H, W, nc), want) < 2e-5
