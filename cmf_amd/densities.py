@@ -320,6 +320,20 @@ class FlowProgram:
         D = int(np.prod(self.tail.x_shape))
         return 4 * nc * (worst + 4 * D)
 
+    def train_bytes_per_sample(self, nc):
+        """Tangent bytes a training step keeps per sample for the backward pass: every layer input of every coupler network
+        (ResNet: 2 K + 1 hidden tensors), the modified rows, the raw output tangent, plus the working set of one layer."""
+        total = 0
+        for m in self.layers:
+            if isinstance(m, AffineCouplingBijection):
+                net = m.net
+                if net.kind == "resnet":
+                    hid, nblk = net.module[0].out_channels, sum(1 for b in net.module if hasattr(b, "conv1"))
+                    total += ((2 * nblk + 1) * hid + 4 * m.cmod + m.geom.C) * m.geom.HW
+                else:
+                    total += sum(l.out_features for l in net if isinstance(l, nn.Linear)) + 4 * m.cmod + m.geom.C
+        return 4 * nc * total + self.tangent_bytes_per_sample(nc)
+
     # -- x -> (z_low, low_dim_elbo, earliest latent) ----------------------------------------------
     def encode(self, x):
         B = x.shape[0]
@@ -826,6 +840,13 @@ class NonSquareHeadDensity(Density):
                 raise ValueError("metric regularisation with hutch_with_cg needs num_hutchinson_samples == "
                                  "latent_dimension (the reference fails at non_square.py:98 otherwise)")
             raise NotImplementedError("g-term on the (B, d, S) Hutchinson product is not built")
+        if want_lik:
+            need = B * prog.train_bytes_per_sample(E.ceil16(prog.d))
+            free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            if need > free:
+                raise RuntimeError(f"cmf_amd: a training step on {B} samples keeps ~{need / 2**30:.0f} GiB of tangents for the backward "
+                                   f"pass but {free / 2**30:.0f} GiB are free; use a smaller per-GPU batch (the reference trains "
+                                   "with 64 samples per GPU) -- recomputation per coupling layer is not built")
         with torch.no_grad():
             x = x.contiguous()
             z_low, low_elbo, u, ctx, pctx = prog.encode_train(x)

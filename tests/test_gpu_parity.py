@@ -682,3 +682,15 @@ def test_hutchinson_surrogate_gradients_match_oracle_autograd():
         loss.backward()
     gn = torch.stack([p.grad.norm() for p in dens.parameters() if p.grad is not None])
     assert torch.isfinite(gn).all() and float(gn.max()) > 0
+
+
+def test_training_memory_guard():
+    """A training batch whose saved tangents cannot fit raises a clear error before anything is launched."""
+    g, meta, cfg, dens = build("mini_mnist")
+    head = find_head(dens)
+    per = head.program.train_bytes_per_sample(16)
+    assert per > 0
+    B = int(400 * 2**30 // per) + 16                                   # > 288 GB worth of saved tangents
+    x = torch.empty(B, 1, 1, 1, device="cuda").expand(B, *g["x"].shape[1:])   # no real storage: the guard fires first
+    with pytest.raises(RuntimeError, match="smaller per-GPU batch"):
+        head.train_forward(x)
