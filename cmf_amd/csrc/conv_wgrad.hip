@@ -39,6 +39,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(cmf_conv_tangent_arg
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = wave & 3, h = wave >> 2;
+  // a wave whose output-channel tile or whose input-channel tiles lie entirely past cout / cin has nothing to add (the
+  // reduction never reads those entries): the 1 -> 64 / 64 -> 2 convs at the ends of a coupler keep 1 - 4 of 8 waves
+  if (co0 + c * 16 >= a.cout || ci0 + (TAPS == 9 ? 0 : h * PAIRS) * 16 >= a.cin) return;
   const int r = lane & 15, q = lane >> 4;
   const int HW = a.H * a.W, nsl = a.nc / 16;
   const long long xsl = a.x_sl ? a.x_sl : 16, ysl = a.y_sl ? a.y_sl : 16;
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_kernel(cmf_conv_tangent_
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = wave & 3, h = wave >> 2;
+  if (co0 + c * 16 >= a.cout || ci0 + 2 * h * 16 >= a.cin) return;  // nothing in range for this wave (no barriers in this kernel)
   const int r = lane & 15, q = lane >> 4;
   const int W = a.W, H = a.H, nsl = a.nc / 16;
   const long long xsl = a.x_sl ? a.x_sl : 16, ysl = a.y_sl ? a.y_sl : 16;
