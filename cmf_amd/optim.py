@@ -32,20 +32,27 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class FlatOptimizer:
+class FlatOptimizer(torch.optim.Optimizer):
+    """A ``torch.optim.Optimizer`` (so ``torch.optim.lr_scheduler.*`` -- the reference's CosineAnnealingLR / LambdaLR,
+    experiment.py:536-552 -- drive it through ``param_groups[0]["lr"]``) whose step is the fused HIP kernel."""
+
     def __init__(self, params, opt="adam", lr=1e-3, weight_decay=0., betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
         if opt not in KINDS:
             raise AssertionError(f"Invalid optimiser type {opt}")       # experiment.py:522
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+        params = [p for p in params if p.requires_grad]
+        if not params:
             raise ValueError("optimizer got an empty parameter list")
+        if params[0].device.type != "cuda":
+            raise RuntimeError("cmf_amd.optim.FlatOptimizer steps through the HIP kernel: parameters must be on the GPU")
+        super().__init__(params, dict(lr=float(lr), weight_decay=float(weight_decay), betas=tuple(betas), eps=float(eps)))
+        self.params = params
         dev = self.params[0].device
         if dev.type != "cuda":
             raise RuntimeError("cmf_amd.optim.FlatOptimizer steps through the HIP kernel: parameters must be on the GPU")
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError("all parameters must be float32 on one device")
-        self.opt, self.lr, self.weight_decay, self.betas, self.eps = opt, float(lr), float(weight_decay), betas, float(eps)
+        self.opt = opt
         self.max_grad_norm = max_grad_norm
         self.t = 0
         # 16-byte aligned slots: every tensor starts on a multiple of 4 floats, the gaps stay zero forever (g = 0 there)
@@ -66,12 +73,19 @@ class FlatOptimizer:
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
 
+    # hyper-parameters live in param_groups[0], where the lr schedulers write them
+    lr = property(lambda self: self.param_groups[0]["lr"], lambda self, v: self.param_groups[0].__setitem__("lr", float(v)))
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"],
+                            lambda self, v: self.param_groups[0].__setitem__("weight_decay", float(v)))
+    betas = property(lambda self: self.param_groups[0]["betas"], lambda self, v: self.param_groups[0].__setitem__("betas", tuple(v)))
+    eps = property(lambda self: self.param_groups[0]["eps"], lambda self, v: self.param_groups[0].__setitem__("eps", float(v)))
+
     # ---- torch.optim.Optimizer surface used by the trainer (trainer.py:207-222) --------------------------------------
-    def zero_grad(self):
+    def zero_grad(self, set_to_none=False):
         self._check_views()
         self.grad.zero_()
 
-    def step(self):
+    def step(self, closure=None):
         self._check_views()
         lib = _lib.load()
         self.t += 1

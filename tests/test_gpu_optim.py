@@ -84,3 +84,29 @@ def test_flat_optimizer_rejects_cpu_parameters():
     from cmf_amd.optim import FlatOptimizer
     with pytest.raises(RuntimeError):
         FlatOptimizer([torch.nn.Parameter(torch.zeros(3))])
+
+
+def test_flat_optimizer_follows_torch_lr_schedulers():
+    """The reference wraps its optimisers in CosineAnnealingLR / LambdaLR (experiment.py:536-552): FlatOptimizer is a
+    torch.optim.Optimizer whose lr lives in param_groups[0], so the same schedulers drive the fused step."""
+    from cmf_amd.optim import FlatOptimizer
+    ref_p, my_p = make_params(5), make_params(5)
+    ref = torch.optim.Adam(ref_p, lr=2e-3)
+    mine = FlatOptimizer(my_p, opt="adam", lr=2e-3)
+    ref_s = torch.optim.lr_scheduler.CosineAnnealingLR(ref, T_max=6, eta_min=0.)
+    my_s = torch.optim.lr_scheduler.CosineAnnealingLR(mine, T_max=6, eta_min=0.)
+    gen = torch.Generator().manual_seed(6)
+    for _ in range(6):
+        ref.zero_grad()
+        mine.zero_grad()
+        for a, b in zip(ref_p, my_p):
+            g = torch.randn(a.shape, generator=gen).cuda()
+            a.grad = g.clone()
+            b.grad.copy_(g)
+        ref.step()
+        mine.step()
+        ref_s.step()
+        my_s.step()
+        assert abs(mine.lr - ref.param_groups[0]["lr"]) < 1e-12
+    for a, b in zip(ref_p, my_p):
+        assert rel(b.data, a.data) < 2e-6

@@ -624,6 +624,7 @@ def test_training_steps_reduce_the_loss():
     import cmf_amd
     from cmf_amd.optim import FlatOptimizer
     g, meta, cfg, dens = build("mini_mnist")
+    dens = inner(dens, True)                       # no dequantisation noise: the loss is a deterministic function of the parameters
     dens.train()
     cfg = dict(cfg, g_ij_loss=True, g_kk_loss=False)
     train_metrics, intro, early = cmf_amd.get_non_square_train_metrics(cfg)
