@@ -132,9 +132,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(cmf_conv_tangent_arg
 // for pixels the same wave loaded one and two steps earlier.  Here wave w owns output-channel tile w & 3 and
 // input-channel tiles {2 (w >> 2), 2 (w >> 2) + 1} for ALL nine taps, walks along image rows, and keeps four image
 // columns (3 rows x 2 channel tiles each) in a register ring: per step ONE new column (6 loads + 6 factor words) and one
-// gy quad are fetched, one step (72 MFMAs) ahead of their first use.  An image row is a stream of W + 2
-// column slots (the zero-padding columns included, as zeros), rows follow each other without a pipeline restart, and
-// everything is branch-free: validity is a select on the loaded values.
+// gy quad are fetched, one step (72 MFMAs) ahead of their first use.  An image row is a stream of
+// column slots with the zero-padding columns included (as zeros), rows follow each other without a pipeline restart, and
+// everything is branch-free: validity is a select on the loaded values.  (A row is W + 1 slots: one zero column between rows.)
 struct WCol {
   f32x4 v[2][3];                                                   // [ci tile][row dy]
   float f[2][3];
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_kernel(cmf_conv_tangent_
   // this workgroup's image rows (row id = (sample * H + y) * nsl + slice) and its slot stream
   const int per = (nrows + gridDim.x - 1) / gridDim.x;
   const int row0 = blockIdx.x * per, row1 = row0 + per < nrows ? row0 + per : nrows;
-  const int nslots = row1 > row0 ? (row1 - row0) * (W + 2) : 0;
+  // W + 1 slots per row: the zero column right of one row doubles as the zero column left of the next (column -1 only)
+  const int nslots = row1 > row0 ? (row1 - row0) * (W + 1) : 0;     // slots past the end are dead = zero columns
 
   // load cursor: the slot the next fetch brings in
   int l_slot = 0, l_col = -1, l_sl = 0, l_yy = 0, l_n = 0;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_kernel(cmf_conv_tangent_
     // advance (branch-free, SALU selects); past the end the cursor stays on the last slot, whose addresses are valid
     const int more = (alive && l_slot + 1 < nslots) ? 1 : 0;
     l_slot += alive ? 1 : 0;
-    const int wrap_c = more && l_col == W;
+    const int wrap_c = more && l_col == W - 1;
     l_col = wrap_c ? -1 : l_col + more;
     const int wrap_s = wrap_c && l_sl + 1 == nsl;
     l_sl = wrap_s ? 0 : l_sl + wrap_c;
