@@ -50,6 +50,7 @@ SIGNATURES = {
     "cmf_conv_tangent_bf16x3": (_i, [C.POINTER(ConvTangentArgs), _fp]),
     "cmf_conv_tangent_wgrad_ws": (_ll, [C.POINTER(ConvTangentArgs)]),
     "cmf_conv_tangent_wgrad": (_i, [C.POINTER(ConvTangentArgs), _fp, _fp, _fp, _ll, _fp]),
+    "cmf_conv_tangent_wgrad_bf16x3": (_i, [C.POINTER(ConvTangentArgs), _fp, _fp, _fp, _ll, _fp]),
     "cmf_primal_regroup": (_i, [_fp, _fp, _i, _ll, _i, _fp]),
     "cmf_conv_primal": (_i, [C.POINTER(ConvPrimalArgs), _fp]),
     "cmf_acl_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),

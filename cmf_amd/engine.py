@@ -252,7 +252,7 @@ _WGRAD_WS = {}
 
 
 def conv_tangent_wgrad(x_t, x_off, x_np, x_ci, x_px, gy_t, gy_off, y_np, y_co, y_px, dw, taps, np_, cin, cout, H, W, nc,
-                       fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, f_group=1, x_sl=16, y_sl=16):
+                       fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, f_group=1, x_sl=16, y_sl=16, precision=None):
     """dw (cout, cin, kh, kw) += weight gradient of the tangent conv described like ``conv_tangent``'s forward launch;
     ``gy_t`` (+ ``gy_off`` elements) is the cotangent of y with y's strides.  fp32 factor tensors only."""
     lib = _lib.load()
@@ -270,8 +270,12 @@ def conv_tangent_wgrad(x_t, x_off, x_np, x_ci, x_px, gy_t, gy_off, y_np, y_co, y
     if ws is None or ws.numel() * 4 < need:
         ws = _WGRAD_WS[key] = torch.empty(need // 4, dtype=torch.float32, device=x_t.device)
     gy = C.c_void_p(gy_t.data_ptr() + 4 * int(gy_off))
-    launch = lambda: _lib.check(lib.cmf_conv_tangent_wgrad(C.byref(a), gy, _p(dw), _p(ws), need, _stream()),
-                                "cmf_conv_tangent_wgrad")
+    # split-precision kernel (operands shared through LDS) where the forward convs use one: whole 64-channel blocks, column pairs
+    split = ((precision or TANGENT_PRECISION) == "bf16x3" and taps == 9 and cin % 64 == 0 and cout % 64 == 0 and nc % 32 == 0
+             and fmode in (F_NONE, F_RELU) and f_group <= 1)
+    fn, what = (lib.cmf_conv_tangent_wgrad_bf16x3, "cmf_conv_tangent_wgrad_bf16x3") if split else \
+               (lib.cmf_conv_tangent_wgrad, "cmf_conv_tangent_wgrad")
+    launch = lambda: _lib.check(fn(C.byref(a), gy, _p(dw), _p(ws), need, _stream()), what)
     if TIMER is None:
         return launch()
     px = float(H) * W * nc * np_
