@@ -189,9 +189,12 @@ __global__ __launch_bounds__(256, 2) void conv_primal_kernel(cmf_conv_primal_arg
           if (a.omode == CMF_O_TANH) {
             v = tanhf(v);
           } else if (a.omode == CMF_O_STANH) {
-            const float t = tanhf(v), w = a.sw[co];
+            // 1 - tanh^2 as sech^2 = 4 e / (1 + e)^2, e = exp(-2 |v|): the difference form loses eps / (1 - t^2) of relative
+            // accuracy when the tanh saturates (logit-scale image inputs drive it there), and g multiplies every tangent
+            // and every gradient below this network
+            const float t = tanhf(v), w = a.sw[co], e = expf(-2.f * fabsf(v));
             v = w * t + a.sb[co];
-            if (gb) gb[co * y_c + gpix * y_px] = w * (1.f - t * t);
+            if (gb) gb[co * y_c + gpix * y_px] = w * (4.f * e / ((1.f + e) * (1.f + e)));
           }
           yb[co * y_c + gpix * y_px] = v;
         }

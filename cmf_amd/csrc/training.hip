@@ -21,7 +21,7 @@ __global__ __launch_bounds__(1024) void stanh_backward_kernel(const float* __res
     const long long e = (i / HW) * C * HW + (long long)c * HW + i % HW;
     const float t = (y[e] - b) * iw, gv = g[e], dyv = dy[e], dgv = dg ? dg[e] : 0.f;
     du[e] = dyv * gv - 2.f * dgv * t * gv;
-    aw += dyv * t + dgv * (1.f - t * t);
+    aw += dyv * t + dgv * (gv * iw);                // 1 - tanh^2 = g / w: no cancellation when the tanh saturates
     ab += dyv;
   }
   aw = block_sum(aw, red);

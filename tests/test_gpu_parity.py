@@ -473,7 +473,7 @@ def test_coupler_net_weight_gradients_match_autograd(name):
             assert rel(grads[m.weight], gw) < 1e-4, (name, type(m).__name__, tuple(m.weight.shape))
 
 
-@pytest.mark.parametrize("name,B", [("mini_mnist", 5), ("mini_cifar", 16)])
+@pytest.mark.parametrize("name,B", [("mini_mnist", 5), ("mini_cifar", 16), ("c3_mnist_full", 3)])
 def test_resnet_coupler_primal_backward_matches_autograd(name, B):
     """f1 building block: primal backward of a ResNet coupler network (ScaledTanh stage, transposed convs with per-column relu',
     weight / bias gradients, input cotangent) on the tangent-conv kernels with 16 samples in the column slots, against
@@ -514,12 +514,14 @@ def test_resnet_coupler_primal_backward_matches_autograd(name, B):
         yy, gg = sw * t + sb, sw * (1 - t * t)
         assert rel(y, yy) < 1e-5 and rel(g, gg) < 1e-4
         want = torch.autograd.grad((yy * dy.double()).sum() + (gg * dg.double()).sum(), p64 + [zd])
+        errs = [rel(grads[p], w.reshape(p.shape)) for p, w in zip(params, want[:-1])]
+        print(f"{name}: dz err {rel(dz, want[-1]):.1e}, parameter gradient errors max {max(errs):.1e} median {sorted(errs)[len(errs) // 2]:.1e}")
         assert rel(dz, want[-1]) < 1e-4
         for p, w in zip(params, want[:-1]):
             assert rel(grads[p], w.reshape(p.shape)) < 1e-4, (name, tuple(p.shape))
 
 
-@pytest.mark.parametrize("name", ["mini_mnist", "mini_cifar", "mini_mnist_small"])
+@pytest.mark.parametrize("name", ["mini_mnist", "mini_cifar", "mini_mnist_small", "c3_mnist_full"])
 def test_head_terms_parameter_gradients_match_oracle_autograd(name):
     """f1: d/d theta and d/d z_low of  sum_b a_b logdet(J^T J) + o_b sum_{i!=j}|G_ij| + r_b ||x_hat - x||^2  at fixed z_low --
     tangent sweep with saved state, Gram backward, reverse sweep with weight gradients, coupling-layer cross terms, primal
@@ -548,18 +550,18 @@ def test_head_terms_parameter_gradients_match_oracle_autograd(name):
     want = torch.autograd.grad(loss, [sd64[k] for k in used] + [zd], allow_unused=True)
     out = head.head_terms_backward(z_low.cuda(), xt.cuda(), g_logdet=a.cuda(), g_l1off=o.cuda(), g_rec=r.cuda())
     assert rel(out["x_hat"], xh) < 1e-5 and rel(out["logdet"], logdet.view(-1)) < 1e-4
-    assert rel(out["dz_low"], want[-1]) < 2e-4
     named = dict(dens.named_parameters())
-    checked = 0
+    errs = []
     for k, w in zip(used, want[:-1]):
         p = named[k]
         if w is None:                                   # parameters outside the decode path (prior flows)
             assert p not in out["grads"]
             continue
         assert p in out["grads"], k
-        assert rel(out["grads"][p], w.reshape(p.shape)) < 5e-4, k
-        checked += 1
-    assert checked >= 30
+        errs.append(rel(out["grads"][p], w.reshape(p.shape)))
+    print(f"{name}: dz_low err {rel(out['dz_low'], want[-1]):.1e}; {len(errs)} tensors, max {max(errs):.1e} median {sorted(errs)[len(errs) // 2]:.1e}")
+    assert rel(out["dz_low"], want[-1]) < 1e-4
+    assert max(errs) < 1e-4 and len(errs) >= 30
 
 
 @pytest.mark.parametrize("name,kw", [
@@ -579,7 +581,7 @@ def test_loss_and_gradients_match_oracle_autograd(name, kw):
     g, meta, cfg, dens = build(name)
     _, schema, x_shape, ops, sd = golden_model(meta, dtype=torch.float64)
     head = find_head(dens)
-    B = 4
+    B = min(4, g["x"].shape[0])
     x = g["x"][:B].double()
     noise = torch.zeros_like(x)
     named = dict(dens.named_parameters())
@@ -591,19 +593,30 @@ def test_loss_and_gradients_match_oracle_autograd(name, kw):
     pre = None if lj_pre is None or not torch.is_tensor(lj_pre) else lj_pre.float().reshape(-1).cuda()
     loss, elbo, grads = head.loss_and_gradients(y.float().cuda(), pre_logjac=pre, **kw)
     assert rel(elbo, want_elbo) < 1e-4 and rel(loss, -want_elbo.mean()) < 1e-4
-    worst, checked = 0.0, 0
+    # The full-size model is NOT in this list on purpose.  Its 4.3 M relu pre-activations per sample include some within fp32
+    # rounding of zero: the HIP chain's layer inputs differ from the float64 oracle's by ~1e-7 relative, ONE activation of the last
+    # encode layer lands on the other side of zero (|a| < 2e-6) and that single mask flip moves every gradient downstream of it by
+    # ~5e-4 (tests/dev/encode_chain_check.py: with the oracle's layer input the same step agrees to 9e-8; tests/dev/
+    # grad_full_check.py: worst 1.5e-2, median 2.5e-4, identical for the fp32 and the split kernels).  That is the exact gradient
+    # of the function fp32 evaluates, not an error of the backward pass -- whose full-size accuracy is pinned flip-free by
+    # test_head_terms_parameter_gradients_match_oracle_autograd[c3_mnist_full] (decode side incl. the split forward / reverse /
+    # weight-gradient kernels: 1.8e-6) and test_encode_layers_backward_full_size (every encode layer on the oracle's inputs).
+    full = name == "c3_mnist_full"
+    errs = {}
     for k, w in zip(keys, want):
         p = named[k]
         if w is None or float(w.abs().max()) == 0.0:
             assert p not in grads or float(grads[p].abs().max()) == 0.0, k
             continue
         assert p in grads, k
-        err = rel(grads[p], w.reshape(p.shape))
-        worst = max(worst, err)
-        assert err < 1e-4, (k, err)
-        checked += 1
+        errs[k] = rel(grads[p], w.reshape(p.shape))
+    worst_key = max(errs, key=errs.get)
+    worst, checked = errs[worst_key], len(errs)
+    median = float(np.median(list(errs.values())))
+    print(f"{name}: {checked} parameter tensors, relative gradient error: worst {worst:.2e} ({worst_key}), median {median:.2e}")
+    assert worst < (5e-2 if full else 1e-4), (worst_key, worst)
+    assert median < (2e-3 if full else 2e-5)
     assert checked >= (40 if len(x_shape) == 3 else 10)
-    print(f"{name}: {checked} parameter tensors, worst relative gradient error {worst:.2e}")
     # the same through autograd, as the reference trainer drives it: elbo -> loss -> loss.backward() -> p.grad
     dens.train()
     dens.zero_grad()
@@ -613,7 +626,7 @@ def test_loss_and_gradients_match_oracle_autograd(name, kw):
         (-out["elbo"].mean()).backward()
     for k, w in zip(keys, want):
         if w is not None and float(w.abs().max()) > 0.0:
-            assert rel(named[k].grad, w.reshape(named[k].shape)) < 1e-4, k
+            assert rel(named[k].grad, w.reshape(named[k].shape)) < (5e-2 if full else 1e-4), k
         else:
             assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0
 
@@ -695,3 +708,48 @@ def test_training_memory_guard():
     x = torch.empty(B, 1, 1, 1, device="cuda").expand(B, *g["x"].shape[1:])   # no real storage: the guard fires first
     with pytest.raises(RuntimeError, match="smaller per-GPU batch"):
         head.train_forward(x)
+
+
+def test_encode_layers_backward_full_size():
+    """Every coupling layer of the full-size MNIST model's ENCODE chain, on the float64 oracle's own layer inputs (so no relu
+    mask can differ): ``encode_train_`` / ``encode_backward_`` -- coupling backward, ScaledTanh stage, primal backward of the
+    64-channel ResNet on the tangent-conv kernels -- against torch.autograd through the oracle's ``acl_x_to_z``."""
+    from oracle import cmf_oracle as O
+    from cmf_amd.bijections import AffineCouplingBijection
+    g, meta, cfg, dens = build("c3_mnist_full")
+    _, schema, x_shape, ops, sd = golden_model(meta, dtype=torch.float64)
+    head = find_head(dens)
+    pmap = dict(dens.named_parameters())
+    pre, hd, flow_ops, base, prior_ops = O.split_ops(ops)
+    x = g["x"][:2].double()
+    h, _ = O.prehead(pre, x, torch.zeros_like(x))
+    gen = torch.Generator().manual_seed(9)
+    acls = iter([m for m in head.program.layers if isinstance(m, AffineCouplingBijection)])
+    for op in flow_ops:
+        k = op["kind"]
+        if k == "flatten":
+            h = h.flatten(1)
+        elif k == "squeeze":
+            h = O.squeeze_x_to_z(h, op["factor"])
+        elif k == "split":
+            h = torch.chunk(h, 2, dim=1)[0]
+        if k != "acl":
+            continue
+        bij = next(acls)
+        keys = [kk for kk in sd if kk.startswith(op["prefix"]) and sd[kk].is_floating_point() and kk in pmap]
+        sd64 = {kk: (v.clone().requires_grad_(True) if kk in keys else v) for kk, v in sd.items()}
+        xin = h.detach().clone().requires_grad_(True)
+        z, _ = O.acl_x_to_z(sd64, op, xin)
+        dz = torch.randn(z.shape, generator=gen).double() * (torch.rand(z.shape, generator=gen) < 0.3).double()
+        want = torch.autograd.grad((z * dz).sum(), [sd64[kk] for kk in keys] + [xin], allow_unused=True)
+        with torch.no_grad():
+            hg = h.detach().float().cuda().contiguous()
+            ctx = bij.encode_train_(hg)
+            assert rel(hg, z) < 1e-6
+            d, grads = dz.float().cuda().contiguous(), {}
+            bij.encode_backward_(d, ctx, grads)
+        assert rel(d, want[-1]) < 2e-6, op["prefix"]
+        for kk, wv in zip(keys, want[:-1]):
+            if wv is not None and float(wv.abs().max()) > 0:
+                assert rel(grads[pmap[kk]], wv.reshape(pmap[kk].shape)) < 5e-6, kk
+        h = z.detach()
