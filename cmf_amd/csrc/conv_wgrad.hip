@@ -295,8 +295,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (e >= per) return;
   const int tap = e % taps, ci = (e / taps) % 64 + ci0, co = e / (taps * 64) + co0;
   if (co >= cout || ci >= cin) return;
-  float s = 0.f;
-  for (int g = 0; g < nwg; ++g) s += ws[(size_t)g * per + e];
+  // eight independent partial sums (the loads of one chain would each wait for the previous add), combined in a fixed order
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int g = 0;
+  for (; g + 8 <= nwg; g += 8)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s8[j] += ws[(size_t)(g + j) * per + e];
+  for (; g < nwg; ++g) s8[0] += ws[(size_t)g * per + e];
+  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   dw[((size_t)co * cin + ci) * taps + tap] += s;
 }
 
