@@ -47,8 +47,6 @@ class FlatOptimizer(torch.optim.Optimizer):
         super().__init__(params, dict(lr=float(lr), weight_decay=float(weight_decay), betas=tuple(betas), eps=float(eps)))
         self.params = params
         dev = self.params[0].device
-        if dev.type != "cuda":
-            raise RuntimeError("cmf_amd.optim.FlatOptimizer steps through the HIP kernel: parameters must be on the GPU")
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError("all parameters must be float32 on one device")
