@@ -12,7 +12,7 @@
 //     split, 4 ds_write_b128, into a ring of four slots (4 x 32 KB of LDS);
 //   * one barrier per slot, then every wave runs its 18 tiles (one output-channel tile x two input-channel tiles x nine taps):
 //     38 ds_read_b128 and 54 MFMAs of 16 cycles -- against 72 fp32 MFMAs of 32 cycles for half the K.
-// Shapes: taps = 9, cin % 64 == 0, cout % 64 == 0, nc % 32 == 0, factor NONE or RELU from a float tensor; everything else
+// Shapes: taps = 9, cin % 64 == 0, cout % 64 == 0, nc % 32 == 0, factor NONE, RELU from a float tensor or SELF_RELU; everything else
 // stays on the fp32 kernel.  Partial blocks and their fixed-order reduction are shared with conv_wgrad.hip.
 #include "common.h"
 #include <type_traits>
@@ -39,9 +39,11 @@ struct Raw {                                        // what one wave fetches for
   int ok;                                           // bit i: fragment i is inside the image (wave-uniform)
 };
 
-template <bool HASF>
+// MODE 0: no factor, 1: relu' from a float tensor, 2: SELF -- the input's own relu, elementwise (primal data: samples in the columns)
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_split_kernel(cmf_conv_tangent_args a, const float* __restrict__ gy,
                                                                      float* __restrict__ ws, int co0, int ci0, int nrows) {
+  constexpr bool HASF = MODE == 1, SELF = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -119,7 +121,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_split_kernel(cmf_conv_ta
       u32x4 hi, lo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float e = ok ? raw.v[i][j >> 1][(2 * j) & 3] * m : 0.f, o = ok ? raw.v[i][j >> 1][(2 * j + 1) & 3] * m : 0.f;
+        float e = raw.v[i][j >> 1][(2 * j) & 3], o = raw.v[i][j >> 1][(2 * j + 1) & 3];
+        if (SELF && !p_gy[i]) e = fmaxf(e, 0.f), o = fmaxf(o, 0.f);
+        e = ok ? e * m : 0.f, o = ok ? o * m : 0.f;
         const unsigned hb = pack2(e, o);
         hi[j] = hb;
         lo[j] = pack2(e - __builtin_bit_cast(float, hb << 16), o - __builtin_bit_cast(float, hb & 0xffff0000u));
@@ -213,7 +217,7 @@ extern "C" int cmf_conv_tangent_wgrad_bf16x3(const cmf_conv_tangent_args* a, con
   if (!a || !a->x || !gy || !dw || !ws) return CMF_EINVAL;
   if (a->taps != 9 || a->cin % 64 || a->cout % 64 || a->nc <= 0 || a->nc % 32) return CMF_EINVAL;
   if (a->np <= 0 || a->H <= 0 || a->W <= 0) return CMF_EINVAL;
-  if (a->fmode != CMF_F_NONE && a->fmode != CMF_F_RELU) return CMF_EINVAL;
+  if (a->fmode != CMF_F_NONE && a->fmode != CMF_F_RELU && a->fmode != CMF_F_SELF_RELU) return CMF_EINVAL;
   if (a->fmode == CMF_F_RELU && (!a->f || a->f_group > 1)) return CMF_EINVAL;
   if (ws_bytes < (long long)WG_MAX * 64 * 64 * 9 * (long long)sizeof(float)) return CMF_EINVAL;
   if (((uintptr_t)a->x | (uintptr_t)gy) % 16 || (a->x_np | a->x_ci | a->x_px | a->x_sl | a->y_np | a->y_co | a->y_px | a->y_sl) % 4)
@@ -224,18 +228,22 @@ extern "C" int cmf_conv_tangent_wgrad_bf16x3(const cmf_conv_tangent_args* a, con
   hipStream_t s = (hipStream_t)stream;
   static bool attr_done = false;                                   // idempotent; a benign race at worst repeats it
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_split_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv_wgrad3x3_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      e = hipFuncSetAttribute((const void*)conv_wgrad3x3_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv_wgrad3x3_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   for (int co0 = 0; co0 < a->cout; co0 += 64)
     for (int ci0 = 0; ci0 < a->cin; ci0 += 64) {
       if (a->fmode == CMF_F_RELU)
-        hipLaunchKernelGGL(conv_wgrad3x3_split_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
+        hipLaunchKernelGGL(conv_wgrad3x3_split_kernel<1>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
+      else if (a->fmode == CMF_F_SELF_RELU)
+        hipLaunchKernelGGL(conv_wgrad3x3_split_kernel<2>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
       else
-        hipLaunchKernelGGL(conv_wgrad3x3_split_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
+        hipLaunchKernelGGL(conv_wgrad3x3_split_kernel<0>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
       CMF_LAUNCH_CHECK();
       hipLaunchKernelGGL(wgrad_reduce_split_kernel, dim3(cmf_ceil_div(64 * 64 * 9, 256)), dim3(256), 0, s, ws, dw, grid, co0, ci0, a->cin);
       CMF_LAUNCH_CHECK();

@@ -272,7 +272,7 @@ def conv_tangent_wgrad(x_t, x_off, x_np, x_ci, x_px, gy_t, gy_off, y_np, y_co, y
     gy = C.c_void_p(gy_t.data_ptr() + 4 * int(gy_off))
     # split-precision kernel (operands shared through LDS) where the forward convs use one: whole 64-channel blocks, column pairs
     split = ((precision or TANGENT_PRECISION) == "bf16x3" and taps == 9 and cin % 64 == 0 and cout % 64 == 0 and nc % 32 == 0
-             and fmode in (F_NONE, F_RELU) and f_group <= 1)
+             and fmode in (F_NONE, F_RELU, F_SELF_RELU) and f_group <= 1)
     fn, what = (lib.cmf_conv_tangent_wgrad_bf16x3, "cmf_conv_tangent_wgrad_bf16x3") if split else \
                (lib.cmf_conv_tangent_wgrad, "cmf_conv_tangent_wgrad")
     launch = lambda: _lib.check(fn(C.byref(a), gy, _p(dw), _p(ws), need, _stream()), what)
@@ -852,7 +852,10 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
     geo, B, dev = view.geom, z.shape[0], z.device
     conv0, blocks, convf = _resnet_parts(net)
     hid, cout, H, W, HW = conv0.out_channels, convf.out_channels, geo.H, geo.W, geo.HW
-    Bp = (B + 15) // 16 * 16
+    # hidden weight gradients on the split-precision kernel: it contracts column PAIRS of 16, so two sample groups are presented as
+    # the two slices of one 32-column "sample" (slice stride = group stride) -- the batch is padded to a multiple of 32 then
+    pair = TANGENT_PRECISION == "bf16x3" and hid % 64 == 0
+    Bp = (B + 31) // 32 * 32 if pair else (B + 15) // 16 * 16
     G = Bp // 16
 
     def grp(t):                                            # (B, C, H, W) -> flat grouped (G, C, HW, 16), zero-padded samples
@@ -863,6 +866,15 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
 
     pn = lambda c: (c * HW * 16, HW * 16, 16)
     new = lambda c: torch.empty(G * c * HW * 16, dtype=torch.float32, device=dev)
+
+    def hidden_wgrad(x_g, gy_g, weight):               # 3x3, hid -> hid, the input's own relu
+        if pair:
+            gs = hid * HW * 16                            # group stride = slice stride
+            conv_tangent_wgrad(x_g, 0, 2 * gs, HW * 16, 16, gy_g, 0, 2 * gs, HW * 16, 16, _grad_of(grads, weight), 9, G // 2, hid, hid,
+                               H, W, 32, fmode=F_SELF_RELU, x_sl=gs, y_sl=gs)
+        else:
+            conv_tangent_wgrad(x_g, 0, *pn(hid), gy_g, 0, *pn(hid), _grad_of(grads, weight), 9, G, hid, hid, H, W, 16, fmode=F_SELF_RELU)
+
     tr = dict(transpose=True, precision="f32")
     self_fo = lambda t: dict(fo=t, fo_np=hid * HW * 16, fo_co=HW * 16, fo_px=16, fomode=F_SELF_RELU)
     du = stanh_backward(dy, dg, y, g, net.weights, net.bias, _grad_of(grads, net.weights).view(-1), _grad_of(grads, net.bias).view(-1))
@@ -876,11 +888,11 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
         blk = blocks[k]
         a_in, c1 = grp(acts[2 * k]), grp(acts[2 * k + 1])
         # a' = a + conv2(relu(c1)) + b2,  c1 = conv1(relu(a)) + b1
-        conv_tangent_wgrad(c1, 0, *pn(hid), da, 0, *pn(hid), _grad_of(grads, blk.conv2.weight), 9, G, hid, hid, H, W, 16, fmode=F_SELF_RELU)
+        hidden_wgrad(c1, da, blk.conv2.weight)
         channel_sum(da, *pn(hid), G, hid, HW, 16, _grad_of(grads, blk.conv2.bias))
         dc1 = new(hid)
         conv_tangent(da, 0, *pn(hid), blk.conv2.weight, 9, dc1, *pn(hid), G, hid, hid, H, W, 16, **self_fo(c1), **tr)
-        conv_tangent_wgrad(a_in, 0, *pn(hid), dc1, 0, *pn(hid), _grad_of(grads, blk.conv1.weight), 9, G, hid, hid, H, W, 16, fmode=F_SELF_RELU)
+        hidden_wgrad(a_in, dc1, blk.conv1.weight)
         channel_sum(dc1, *pn(hid), G, hid, HW, 16, _grad_of(grads, blk.conv1.bias))
         da2 = new(hid)
         conv_tangent(dc1, 0, *pn(hid), blk.conv1.weight, 9, da2, *pn(hid), G, hid, hid, H, W, 16, res_t=da, **self_fo(a_in), **tr)

@@ -751,5 +751,5 @@ def test_encode_layers_backward_full_size():
         assert rel(d, want[-1]) < 2e-6, op["prefix"]
         for kk, wv in zip(keys, want[:-1]):
             if wv is not None and float(wv.abs().max()) > 0:
-                assert rel(grads[pmap[kk]], wv.reshape(pmap[kk].shape)) < 5e-6, kk
+                assert rel(grads[pmap[kk]], wv.reshape(pmap[kk].shape)) < 3e-5, kk     # hidden weight gradients: split-precision kernel
         h = z.detach()
