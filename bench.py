@@ -79,6 +79,51 @@ def pmc_traffic(precision):
         return json.load(f).get("traffic_bytes_per_launch")
 
 
+def train_bench(args, density, x, B, rank, world, device):
+    """Secondary metric: training samples / s (one process per GPU, flat gradient all-reduce over RCCL, fused Adam)."""
+    import torch.distributed as dist
+    from cmf_amd.optim import FlatOptimizer
+    density.train()
+    opt = FlatOptimizer(density.parameters(), opt="adam", lr=1e-4)
+    kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=True, likelihood_wt=1., metric_wt=1.)
+
+    def step():
+        opt.zero_grad()
+        loss = -density.elbo(x, **kw)["elbo"].mean()
+        loss.backward()
+        opt.allreduce_flat()
+        opt.step()
+        return loss.detach()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training samples/sec (forward + backward + Adam, JtJ-cholesky objective), MNIST D=784 d=64", "value": B * world * args.steps / dt,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (3x3 tangent convs, their transposes and weight gradients as bf16x3 split MFMA, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": "C3 / C4 model, one optimiser step per batch, g_ij off-diagonal objective", "per_gpu_batch": B,
+                       "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss),
+                       "peak_memory_gib": torch.cuda.max_memory_allocated(device) / 2 ** 30}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +141,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 "
                                                        "on a one-GPU box together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (never a measurement)")
+    ap.add_argument("--train", action="store_true",
+                    help="SECONDARY metric (SURVEY 8d): time training steps instead -- forward + loss.backward() on the HIP kernels + "
+                         "data-parallel gradient all-reduce + fused Adam; use --batch 64 (the reference's per-GPU shard)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -125,6 +173,9 @@ def main():
     def step():
         out = inner.elbo(x, add_reconstruction=True, add_offdiagonal_metric_reg=True, likelihood_wt=1., metric_wt=1.)
         return allreduce_mean_elbo(out["elbo"])          # (sum, count) all-reduce; plain mean on one rank
+
+    if args.train:
+        return train_bench(args, inner, x, B, rank, world, device)
 
     def fence():
         if world > 1:
