@@ -159,10 +159,15 @@ class AffineCouplingBijection(Bijection):
         E.net_cotangent(self.net, YC, self.view(dev), acts, Ct)
 
     # training: decode keeping what the backward needs, and the backward of that step ------------
-    def decode_train_(self, z, T):
+    def decode_train_(self, z, T, keep=True):
         """``decode_`` on (z, T) in place; returns the context ``decode_backward_`` consumes: the layer input, the network's
         outputs and activations and, with a tangent stack (``T`` not None), every layer's input tangent, the modified tangent
-        rows before the update and the network's raw tangent."""
+        rows before the update and the network's raw tangent.  ``keep=False`` (recomputation): only the layer's inputs (z and a
+        copy of T: 1/17 of the hidden tangents of a ResNet coupler) are kept and the context is rebuilt in the backward pass."""
+        if not keep and T is not None:
+            ctx = ("recompute", z.clone(), E.Tangent(T.B, T.N, T.nc, T.layout, T.data.device, data=T.data[: T.B * T.N * T.nc].clone()))
+            self.decode_(z, T)
+            return ctx
         view, maps = self.view(z.device), self.maps(z.device)
         zb = z.clone()
         y, g, acts = E.net_primal(self.net, z, view, need_acts=True)
@@ -179,6 +184,8 @@ class AffineCouplingBijection(Bijection):
         """Backward of ``decode_train_``: ``Ct`` (cotangent of the tangent stack, or None) and ``dx`` (cotangent of the primal
         tensor) are updated in place from "after the layer" to "before the layer"; parameter gradients accumulate into ``grads``
         (dict parameter -> tensor).  Order matters: the cross terms read the cotangent of the UPDATED tangent rows."""
+        if ctx[0] == "recompute":                          # rebuild this layer's state from its inputs (one more tangent sweep)
+            ctx = self.decode_train_(ctx[1], ctx[2], keep=True)
         zb, y, g, acts, saved, V, YT = ctx
         dev = zb.device
         view, maps = self.view(dev), self.maps(dev)

@@ -320,19 +320,22 @@ class FlowProgram:
         D = int(np.prod(self.tail.x_shape))
         return 4 * nc * (worst + 4 * D)
 
-    def train_bytes_per_sample(self, nc):
+    def train_bytes_per_sample(self, nc, recompute=False):
         """Tangent bytes a training step keeps per sample for the backward pass: every layer input of every coupler network
-        (ResNet: 2 K + 1 hidden tensors), the modified rows, the raw output tangent, plus the working set of one layer."""
-        total = 0
+        (ResNet: 2 K + 1 hidden tensors), the modified rows, the raw output tangent, plus the working set of one layer.
+        ``recompute``: only the largest coupler's state at a time, plus one copy of the tangent stack per layer."""
+        total, worst = 0, 0
         for m in self.layers:
             if isinstance(m, AffineCouplingBijection):
                 net = m.net
                 if net.kind == "resnet":
                     hid, nblk = net.module[0].out_channels, sum(1 for b in net.module if hasattr(b, "conv1"))
-                    total += ((2 * nblk + 1) * hid + 4 * m.cmod + m.geom.C) * m.geom.HW
+                    one = ((2 * nblk + 1) * hid + 4 * m.cmod + m.geom.C) * m.geom.HW
                 else:
-                    total += sum(l.out_features for l in net if isinstance(l, nn.Linear)) + 4 * m.cmod + m.geom.C
-        return 4 * nc * total + self.tangent_bytes_per_sample(nc)
+                    one = sum(l.out_features for l in net if isinstance(l, nn.Linear)) + 4 * m.cmod + m.geom.C
+                worst = max(worst, one)
+                total += m.geom.N if recompute else one
+        return 4 * nc * (total + (worst if recompute else 0)) + self.tangent_bytes_per_sample(nc)
 
     # -- x -> (z_low, low_dim_elbo, earliest latent) ----------------------------------------------
     def encode(self, x):
@@ -415,8 +418,9 @@ class FlowProgram:
         return z, out.to_dense(S).contiguous()
 
     # -- training: decode with saved state, and its backward -------------------------------
-    def decode_train(self, z_low, tangents=True):
-        """``decode(z_low, tangents)`` keeping every coupling layer's context; returns (x_hat, T, ctx)."""
+    def decode_train(self, z_low, tangents=True, keep=True):
+        """``decode(z_low, tangents)`` keeping every coupling layer's context (``keep=False``: only its inputs, the rest is
+        recomputed layer by layer in ``decode_backward``); returns (x_hat, T, ctx)."""
         B, dev = z_low.shape[0], z_low.device
         N = int(np.prod(self.tail.x_shape))
         scatter = self.tail.scatter_index(dev)
@@ -425,7 +429,7 @@ class FlowProgram:
         ctx = []
         for m in reversed(self.layers):
             if isinstance(m, AffineCouplingBijection):
-                ctx.append(m.decode_train_(z, T))
+                ctx.append(m.decode_train_(z, T, keep))
             elif isinstance(m, SplitDensity):
                 n = z[0].numel()
                 idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),
@@ -770,13 +774,13 @@ class NonSquareHeadDensity(Density):
     # ------------------------------------------------------------------------------------------
     # training: forward with saved state, backward on the HIP kernels
     # ------------------------------------------------------------------------------------------
-    def head_terms_forward(self, z_low, tangents=True, hutch_eps=None):
+    def head_terms_forward(self, z_low, tangents=True, hutch_eps=None, keep=True):
         """Decode (with the Jacobian stack) keeping every layer's context, Gram + Cholesky; returns the state
         ``head_terms_backward`` consumes.  ``hutch_eps`` (B, d, S): also run the Hutchinson + CG surrogate of
         non_square.py:203-258 on the explicit Gram matrix (train mode of ``log_jacobian_method = "hutch_with_cg"``)."""
         E.require_gpu(z_low)
         with torch.no_grad():
-            x_hat, T, ctx = self.program.decode_train(z_low.detach(), tangents)
+            x_hat, T, ctx = self.program.decode_train(z_low.detach(), tangents, keep)
             gr = hutch = None
             if tangents:
                 gr = E.gram_cholesky(T, self.program.d)
@@ -823,6 +827,10 @@ class NonSquareHeadDensity(Density):
             out["logdet"] = st["hutch"]["value"]
         return out
 
+    #: None = decide from the free HBM; True = always rebuild each coupling layer's tangent state in the backward pass (one more
+    #: forward tangent sweep, 1/10 of the memory for a ten-coupler model); False = keep everything
+    recompute = None
+
     def train_forward(self, x, add_reconstruction=True, add_diagonal_metric_reg=False, add_offdiagonal_metric_reg=False,
                       likelihood_wt=1., metric_wt=1., pre_logjac=None):
         """Forward half of a training step: ``elbo`` (B, 1) exactly as ``_elbo`` computes it on the exact path, plus the state
@@ -840,17 +848,21 @@ class NonSquareHeadDensity(Density):
                 raise ValueError("metric regularisation with hutch_with_cg needs num_hutchinson_samples == "
                                  "latent_dimension (the reference fails at non_square.py:98 otherwise)")
             raise NotImplementedError("g-term on the (B, d, S) Hutchinson product is not built")
+        keep = True
         if want_lik:
-            need = B * prog.train_bytes_per_sample(E.ceil16(prog.d))
+            nc = E.ceil16(prog.d)
             free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            keep = (B * prog.train_bytes_per_sample(nc) <= 0.8 * free) if self.recompute is None else not self.recompute
+            need = B * prog.train_bytes_per_sample(nc, recompute=not keep)
             if need > free:
                 raise RuntimeError(f"cmf_amd: a training step on {B} samples keeps ~{need / 2**30:.0f} GiB of tangents for the backward "
-                                   f"pass but {free / 2**30:.0f} GiB are free; use a smaller per-GPU batch (the reference trains "
-                                   "with 64 samples per GPU) -- recomputation per coupling layer is not built")
+                                   f"pass (recomputation per coupling layer {'on' if not keep else 'off'}) but {free / 2**30:.0f} GiB "
+                                   "are free; use a smaller per-GPU batch (the reference trains with 64 samples per GPU)")
         with torch.no_grad():
             x = x.contiguous()
             z_low, low_elbo, u, ctx, pctx = prog.encode_train(x)
-            head = self.head_terms_forward(z_low, tangents=want_lik, hutch_eps=self._hutchinson_probes(B, dev) if hutch else None)
+            head = self.head_terms_forward(z_low, tangents=want_lik, hutch_eps=self._hutchinson_probes(B, dev) if hutch else None,
+                                           keep=keep)
             gr = head["gram"]
             rec = E.recon_sqerr(head["x_hat"], x) if add_reconstruction else None
             l1 = logdet = None

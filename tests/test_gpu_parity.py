@@ -706,8 +706,29 @@ def test_training_memory_guard():
     assert per > 0
     B = int(400 * 2**30 // per) + 16                                   # > 288 GB worth of saved tangents
     x = torch.empty(B, 1, 1, 1, device="cuda").expand(B, *g["x"].shape[1:])   # no real storage: the guard fires first
+    head.recompute = False                                             # (None would switch to recomputation per coupling layer)
     with pytest.raises(RuntimeError, match="smaller per-GPU batch"):
         head.train_forward(x)
+    head.recompute = None
+    assert head.program.train_bytes_per_sample(16, recompute=True) < per / 3
+
+
+@pytest.mark.parametrize("name", ["mini_mnist", "c3_mnist_full"])
+def test_recomputation_per_coupling_layer_gives_the_same_gradients(name):
+    """``head.recompute = True``: each coupling layer keeps only its inputs and rebuilds its tangent state in the backward pass
+    (the same kernels on the same data): identical loss, gradients equal to rounding."""
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    x = g["head_input"][:2].float().cuda() if "head_input" in g else g["x"][:2].float().cuda()
+    kw = dict(add_offdiagonal_metric_reg=True)
+    head.recompute = False
+    loss_a, elbo_a, grads_a = head.loss_and_gradients(x.clone(), **kw)
+    head.recompute = True
+    loss_b, elbo_b, grads_b = head.loss_and_gradients(x.clone(), **kw)
+    head.recompute = None
+    assert torch.equal(elbo_a, elbo_b) and set(grads_a) == set(grads_b)
+    for p in grads_a:
+        assert rel(grads_b[p], grads_a[p]) < 1e-6
 
 
 def test_encode_layers_backward_full_size():
