@@ -11,6 +11,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     if (e_ != hipSuccess) return (int)e_;          \
   } while (0)
 
+// runtime.hip: per-(device, kernel) memo of the dynamic-LDS attribute and the per-device CU count (keyed by the calling
+// thread's current device; see the file header for why a process-wide flag is wrong)
+hipError_t cmf_set_dynamic_lds(const void* fn, int bytes);
+int cmf_device_cus();
+
 static inline int cmf_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // sum over the 64 lanes of a wavefront (every lane gets the total)

@@ -817,15 +817,8 @@ int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   if (total > 0x7fffffffLL) return CMF_ERANGE;
   auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE>;
   constexpr int lds = C::LDS_BYTES;
-  static int n_cu = 0;                          // idempotent initialisation; a benign race at worst repeats it
-  if (n_cu == 0) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      cus = 256;
-    n_cu = cus > 0 ? cus : 256;
-  }
+  if (hipError_t e = cmf_set_dynamic_lds((const void*)k, lds); e != hipSuccess) return (int)e;   // per device (runtime.hip)
+  const int n_cu = cmf_device_cus();
   int grid = (int)(total < n_cu ? total : n_cu);                // persistent: one 112 KiB workgroup per CU
 #ifdef CMF_DBG_STAMP
   if (const char* e = getenv("CMF_DBG_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;   // diagnostic: fewer active CUs

@@ -226,15 +226,11 @@ extern "C" int cmf_conv_tangent_wgrad_bf16x3(const cmf_conv_tangent_args* a, con
   if (nrows > 0x7fffffffLL / (a->W + 2)) return CMF_ERANGE;
   const int grid = (int)(nrows < WG_MAX ? nrows : WG_MAX);
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_done = false;                                   // idempotent; a benign race at worst repeats it
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad3x3_split_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv_wgrad3x3_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv_wgrad3x3_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  {                                                                // per (device, kernel) memo: runtime.hip
+    hipError_t e = cmf_set_dynamic_lds((const void*)conv_wgrad3x3_split_kernel<0>, LDS_BYTES);
+    if (e == hipSuccess) e = cmf_set_dynamic_lds((const void*)conv_wgrad3x3_split_kernel<1>, LDS_BYTES);
+    if (e == hipSuccess) e = cmf_set_dynamic_lds((const void*)conv_wgrad3x3_split_kernel<2>, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
   }
   for (int co0 = 0; co0 < a->cout; co0 += 64)
     for (int ci0 = 0; ci0 < a->cin; ci0 += 64) {

@@ -110,7 +110,7 @@ extern "C" int cmf_gram_backward(const float* t, long long t_b, long long t_r, i
   if ((t_b | t_r | dt_b | dt_r) % 4 || (uintptr_t)t % 16 || (uintptr_t)dt % 16) return CMF_EINVAL;
   const size_t lds = ((size_t)d * (nc + 4) + 2 * nc + (size_t)SLAB * nc) * sizeof(float);
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)gram_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cmf_set_dynamic_lds((const void*)gram_backward_kernel, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(gram_backward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, t, t_b, t_r, n_rows, nc, d, jtj,
@@ -126,7 +126,7 @@ extern "C" int cmf_gram_backward_matrix(const float* t, long long t_b, long long
   if ((t_b | t_r | dt_b | dt_r) % 4 || (uintptr_t)t % 16 || (uintptr_t)dt % 16) return CMF_EINVAL;
   const size_t lds = ((size_t)d * (nc + 4) + 2 * nc + (size_t)SLAB * nc) * sizeof(float);
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)gram_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cmf_set_dynamic_lds((const void*)gram_backward_kernel, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(gram_backward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, t, t_b, t_r, n_rows, nc, d, m,

@@ -374,7 +374,7 @@ int launch_gram_direct(const float* t, long long t_b, long long t_r, int n_rows,
   const size_t lds = (size_t)(NC * (NC + 1)) * sizeof(float) * (NT == 4 ? 4 : 1);
   auto k = gram_chol_direct_kernel<NT>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cmf_set_dynamic_lds((const void*)k, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(k, dim3(B), dim3(256), lds, s, t, t_b, t_r, n_rows, d, jtj, logdet, l1_off, l1_diag, info, fail);
@@ -394,7 +394,7 @@ int launch_gram(const float* t, long long t_b, long long t_r, int n_rows, int d,
   const size_t lds = (size_t)(KC * LDJ + NC * (NC + 1)) * sizeof(float);
   auto k = gram_chol_kernel<NT>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cmf_set_dynamic_lds((const void*)k, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(k, dim3(B), dim3(256), lds, s, t, t_b, t_r, n_rows, d, jtj, logdet, l1_off, l1_diag, info, fail);
@@ -435,7 +435,7 @@ extern "C" int cmf_cholesky_retry(float* jtj, int d, int B, int attempt, float e
   for (int i = 1; i < attempt; ++i) eps *= 10.f;
   const size_t lds = (size_t)d * (d + 1) * sizeof(float);
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)chol_retry_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cmf_set_dynamic_lds((const void*)chol_retry_kernel, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(chol_retry_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, jtj, d, attempt, eps, logdet,

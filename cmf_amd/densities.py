@@ -359,6 +359,56 @@ class FlowProgram:
         self.gaussian.logprob_accumulate(u, lj)
         return z_low, lj, u
 
+    def encode_nested(self, x):
+        """``encode`` that also rebuilds the reference's NESTED ``prior-dict`` (non_square.py:126-129 returns the dict of
+        ``self.prior.elbo(x)``: one level per module of the chain -- exact.py:23-30 ``{"elbo", "bijection-info": {"z",
+        "log-jac"}, "prior-dict"}``, split.py:15-24 ``{"elbo", "prior-dict", "prior-dict-2"}``, non_square.py:381-395
+        ``{"elbo", "low-dim-x", "prior-dict"}``, gaussian.py:65-74 ``{"elbo", "z"}``).  Opt-in (``head.nested_prior_dict``):
+        every level costs a copy of the current tensor and a log-jacobian reduction the log-density itself never reads
+        (the reference discards them, non_square.py:157-158,177).  Returns (z_low, low_dim_elbo, u, nested dict)."""
+        B, dev = x.shape[0], x.device
+        zeros = lambda: torch.zeros(B, dtype=torch.float32, device=dev)
+        h = x.detach().clone().contiguous()
+        levels = []                                  # (kind, contribution to the elbo (B,), payload)
+        for m in self.layers:
+            if isinstance(m, AffineCouplingBijection):
+                lj = zeros()
+                m.encode_(h, lj)
+                levels.append(("bijection", lj, h.clone()))
+            elif isinstance(m, SplitDensity):
+                n = h[0].numel() // 2
+                h2 = E.gather_primal(h, torch.arange(n, 2 * n, dtype=torch.int32, device=dev), n)
+                h2 = h2.view(B, h.shape[1] // 2, *h.shape[2:])
+                lp2 = zeros()
+                m.density_2.logprob_accumulate(h2, lp2)
+                h = E.gather_primal(h, torch.arange(n, dtype=torch.int32, device=dev), n).view(B, h.shape[1] // 2, *h.shape[2:])
+                levels.append(("split", lp2, h2))
+            else:
+                h = m.encode(h)
+                levels.append(("bijection", zeros(), h.clone()))
+        z_low = E.gather_primal(h, self.tail.gather_index(dev), self.d)
+        levels.append(("tail", zeros(), z_low))
+        u = z_low.clone()
+        for m in self.prior:
+            lj = zeros()
+            if isinstance(m, (AffineCouplingBijection, AffineBijection)):
+                m.encode_(u, lj)
+            levels.append(("bijection", lj, u.clone()))
+        lp = zeros()
+        self.gaussian.logprob_accumulate(u, lp)
+        node, acc = {"elbo": lp.view(B, 1), "z": u}, lp
+        low_elbo = None
+        for kind, c, payload in reversed(levels):
+            acc = acc + c
+            if kind == "bijection":
+                node = {"elbo": acc.view(B, 1), "bijection-info": {"z": payload, "log-jac": c.view(B, 1)}, "prior-dict": node}
+            elif kind == "split":
+                node = {"elbo": acc.view(B, 1), "prior-dict": node, "prior-dict-2": {"elbo": c.view(B, 1), "z": payload}}
+            else:
+                low_elbo = acc
+                node = {"elbo": acc.view(B, 1), "low-dim-x": payload, "prior-dict": node}
+        return z_low, low_elbo, u, node
+
     # -- z_low -> (x_hat, J) ----------------------------------------------------------------------
     def decode(self, z_low, tangents=True, eps=None):
         B, dev = z_low.shape[0], z_low.device
@@ -567,6 +617,14 @@ class NonSquareTailDensity(Density):
         return self.prior.extract_latent(x, **kwargs)
 
 
+def _cat_nested(outs):
+    """Concatenate the result dicts of sub-batches along dim 0, recursing into nested dicts."""
+    first = outs[0]
+    if isinstance(first, dict):
+        return {k: _cat_nested([o[k] for o in outs]) for k in first}
+    return torch.cat(outs)
+
+
 class _ElboFunction(torch.autograd.Function):
     """elbo (B, 1) of a NonSquareHeadDensity as one autograd node over the head's parameters: forward =
     ``train_forward`` (saved state instead of an autograd tape), backward = ``train_backward`` on the HIP kernels."""
@@ -575,11 +633,15 @@ class _ElboFunction(torch.autograd.Function):
     def forward(ctx, head, x, kw, pre, box, *params):
         elbo, state = head.train_forward(x, pre_logjac=pre, **kw)
         ctx.head, ctx.state, ctx.params = head, state, params
-        box["prior-dict"] = {"low-dim-x": state["z_low"]}
+        box["prior-dict"] = state["prior_dict"]            # same keys / nesting as the no-grad path
         return elbo
 
     @staticmethod
     def backward(ctx, d_elbo):
+        if ctx.state is None:
+            raise RuntimeError("cmf_amd: backward through this elbo a second time: the saved tangent state (the bulk of the step's "
+                               "memory) is released after the first backward; retain_graph / double backward are not supported -- "
+                               "call elbo() again")
         grads = ctx.head.train_backward(ctx.state, d_elbo)
         ctx.state = None                                   # the saved tangents are the bulk of the step's memory
         return (None, None, None, None, None, *[grads.get(p) for p in ctx.params])
@@ -592,6 +654,10 @@ class NonSquareHeadDensity(Density):
     _VALID_LOG_JACOBIAN_METHODS = ["cholesky", "hutch_with_cg"]
     MAX_ATTEMPTS = 6        # the reference declares it (non_square.py:265) but loops forever; we stop here
     _jacobian_free = False   # M-flow baseline: likelihood term without the log-det (non_square.py:341-346)
+    #: False: ``prior-dict`` = the flat ``{"elbo": low_dim_elbo, "low-dim-x": z_low}`` the log-density path itself needs (what
+    #: ``_traverse_backward`` digs out of the chain, non_square.py:157-177); True: the reference's full nested chain of dicts
+    #: (``FlowProgram.encode_nested``), for callers that walk it
+    nested_prior_dict = False
     check_cholesky = "sync"  # "sync": read the retry flags after each call (warn / raise like the reference);
     #                          "lazy": never synchronise; attempts are left in ``last_gram.fail`` on the device
 
@@ -662,31 +728,33 @@ class NonSquareHeadDensity(Density):
                 for i in range(0, B, chunk)]
         if len(outs) == 1:
             return outs[0]
-        merged = {k: torch.cat([o[k] for o in outs]) for k in outs[0] if k != "prior-dict"}
-        if "prior-dict" in outs[0]:
-            merged["prior-dict"] = {k: torch.cat([o["prior-dict"][k] for o in outs]) for k in outs[0]["prior-dict"]}
-        return merged
+        return _cat_nested(outs)
 
     def _elbo_chunk(self, x, want_lik, want_jac, add_rec, add_diag, add_off, lw, mw, ood, pre):
         prog, B, dev = self.program, x.shape[0], x.device
         x = x.contiguous()
-        z_low, low_elbo, _ = prog.encode(x)
+        if self.nested_prior_dict:
+            z_low, low_elbo, _, prior_dict = prog.encode_nested(x)
+        else:
+            z_low, low_elbo, _ = prog.encode(x)
+            prior_dict = {"elbo": low_elbo.view(B, 1), "low-dim-x": z_low}
         logdet = l1 = None
         if want_jac:
             x_hat, T = prog.decode(z_low, tangents=True)
-            g = E.gram_cholesky(T, prog.d, self.MAX_ATTEMPTS)
+            hutch = self.training and self.log_jacobian_method == "hutch_with_cg"
+            # the Hutchinson branch never factorises (non_square.py:203-258): no jitter may touch its Gram matrix
+            g = E.gram_cholesky(T, prog.d, 1 if hutch else self.MAX_ATTEMPTS)
             self.last_gram = g
-            if self.training and self.log_jacobian_method == "hutch_with_cg":
+            if hutch:
                 # train mode: Hutchinson + CG surrogate (non_square.py:131-138, :203-258) on the explicit Gram matrix
-                if add_diag or add_off:
-                    if self.num_hutchinson_samples != prog.d:
-                        raise ValueError("metric regularisation with hutch_with_cg needs num_hutchinson_samples == "
-                                         "latent_dimension (the reference fails at non_square.py:98 otherwise)")
-                    raise NotImplementedError("g-term on the (B, d, S) Hutchinson product is not built")
+                self._check_hutchinson_metric(add_diag or add_off)
                 eps = self._hutchinson_probes(B, dev)
                 val, u, w, iters = E.hutch_cg(g.jtj, eps, self.max_cg_iterations or prog.d, self.cg_tolerance)
                 self.last_hutchinson = {"eps": eps, "u": u, "w": w, "iterations": iters, "value": val}
                 logdet = val
+                if add_diag or add_off:                       # g-term on the product (J^T J) eps, S == d (non_square.py:87-100)
+                    l1_off, l1_diag = E.hutch_metric(w)
+                    l1 = l1_diag if add_diag else l1_off
             else:
                 self._report_attempts(g)
                 logdet = g.logdet
@@ -699,7 +767,14 @@ class NonSquareHeadDensity(Density):
             return {"likelihood": lik, "reconstruction-error": rec.view(B, 1)}
         elbo = E.elbo_combine(low_elbo if want_lik else None, logdet, rec, l1, pre, lw, self.regularization_param, mw,
                               B, dev)
-        return {"elbo": elbo, "prior-dict": {"elbo": low_elbo.view(B, 1), "low-dim-x": z_low}}
+        return {"elbo": elbo, "prior-dict": prior_dict}
+
+    def _check_hutchinson_metric(self, wanted):
+        """The reference reshapes the off-diagonal entries of the (B, d, S) product to (B, d (d - 1)) (non_square.py:98): only
+        S == d survives that view (the diagonal variant too reads ``diagonal(dim1=-2, dim2=-1)`` of a square block)."""
+        if wanted and self.num_hutchinson_samples != self.program.d:
+            raise ValueError("metric regularisation with hutch_with_cg needs num_hutchinson_samples == "
+                             "latent_dimension (the reference fails at non_square.py:98 otherwise)")
 
     def _hutchinson_probes(self, B, dev):
         """non_square.py:204-213: N(0,1) or Rademacher probes of shape (B, d, S)."""
@@ -783,12 +858,18 @@ class NonSquareHeadDensity(Density):
             x_hat, T, ctx = self.program.decode_train(z_low.detach(), tangents, keep)
             gr = hutch = None
             if tangents:
-                gr = E.gram_cholesky(T, self.program.d)
-                if int(gr.fail[0].item()) != 0:
-                    raise RuntimeError("J^T J is not positive definite at the first attempt: the jittered retries are not differentiated")
+                # Non-PD batches train on like the reference (non_square.py:280-288, called with create_graph=self.training):
+                # the retries enqueued by gram_cholesky add eps I to every sample's G IN PLACE, the jitter is a constant, so
+                # the gradient simply flows through the jittered matrix -- which is the ``jtj`` gram_backward inverts.
+                gr = E.gram_cholesky(T, self.program.d, 1 if hutch_eps is not None else self.MAX_ATTEMPTS)
+                self.last_gram = gr
+                if hutch_eps is None:
+                    self._report_attempts(gr)               # warn like the reference; raise only after MAX_ATTEMPTS
                 if hutch_eps is not None:
                     val, u, w, iters = E.hutch_cg(gr.jtj, hutch_eps, self.max_cg_iterations or self.program.d, self.cg_tolerance)
                     hutch = {"eps": hutch_eps, "u": u, "w": w, "iterations": iters, "value": val}
+                    if hutch_eps.shape[2] == self.program.d:
+                        hutch["l1_off"], hutch["l1_diag"] = E.hutch_metric(w)
                     self.last_hutchinson = hutch
         return {"x_hat": x_hat, "T": T, "ctx": ctx, "gram": gr, "hutch": hutch}
 
@@ -808,11 +889,9 @@ class NonSquareHeadDensity(Density):
             if tangents and st.get("hutch") is not None:
                 # surrogate value_b = mean_s u_s^T (G eps_s) with u detached (the CG solve runs under no_grad in the reference,
                 # non_square.py:236-247): d value / d G = mean_s u_s eps_s^T, handed over as an explicit matrix
-                if g_l1off is not None or g_l1diag is not None:
-                    raise NotImplementedError("g-term on the (B, d, S) Hutchinson product is not built")
+                # and the metric term on the product W = G eps (S == d): d |W_is| / d G = sign(W_is) e_i eps_s^T
                 h = st["hutch"]
-                S = h["eps"].shape[2]
-                M = torch.einsum("bis,bjs->bij", h["u"], h["eps"]) * (g_logdet.to(torch.float32) / S).view(B, 1, 1)
+                M = E.hutch_cotangent(h["u"], h["eps"], h["w"], g_logdet, g_l1off, g_l1diag)
                 Ct = E.gram_backward_matrix(T, M)
             elif tangents:
                 Ct = E.gram_backward(T, gr.jtj, g_logdet, g_l1off, g_l1diag)
@@ -843,11 +922,8 @@ class NonSquareHeadDensity(Density):
         prog, B, dev = self.program, x.shape[0], x.device
         want_lik = not np.isclose(likelihood_wt, 0.)
         hutch = want_lik and self.training and self.log_jacobian_method == "hutch_with_cg"     # non_square.py:131-138
-        if hutch and (add_diagonal_metric_reg or add_offdiagonal_metric_reg):
-            if self.num_hutchinson_samples != prog.d:
-                raise ValueError("metric regularisation with hutch_with_cg needs num_hutchinson_samples == "
-                                 "latent_dimension (the reference fails at non_square.py:98 otherwise)")
-            raise NotImplementedError("g-term on the (B, d, S) Hutchinson product is not built")
+        if hutch:
+            self._check_hutchinson_metric(add_diagonal_metric_reg or add_offdiagonal_metric_reg)
         keep = True
         if want_lik:
             nc = E.ceil16(prog.d)
@@ -867,11 +943,13 @@ class NonSquareHeadDensity(Density):
             rec = E.recon_sqerr(head["x_hat"], x) if add_reconstruction else None
             l1 = logdet = None
             if want_lik:
-                l1 = gr.l1_diag if add_diagonal_metric_reg else (gr.l1_off if add_offdiagonal_metric_reg else None)
+                src = head["hutch"] if hutch else {"l1_off": gr.l1_off, "l1_diag": gr.l1_diag}
+                l1 = src["l1_diag"] if add_diagonal_metric_reg else (src["l1_off"] if add_offdiagonal_metric_reg else None)
                 logdet = head["hutch"]["value"] if hutch else gr.logdet
             elbo = E.elbo_combine(low_elbo if want_lik else None, logdet, rec, l1, pre_logjac,
                                   likelihood_wt, self.regularization_param, metric_wt, B, dev)
-        state = dict(x=x, z_low=z_low, u=u, ctx=ctx, pctx=pctx, head=head, want_lik=want_lik, rec=add_reconstruction,
+        prior_dict = {"elbo": low_elbo.view(B, 1), "low-dim-x": z_low}
+        state = dict(x=x, z_low=z_low, u=u, ctx=ctx, pctx=pctx, head=head, want_lik=want_lik, rec=add_reconstruction, prior_dict=prior_dict,
                      diag=add_diagonal_metric_reg, off=add_offdiagonal_metric_reg, wl=float(likelihood_wt), wm=float(metric_wt))
         return elbo, state
 

@@ -44,16 +44,23 @@ def allreduce_mean_elbo(elbo):
     return acc[0] / acc[1]
 
 
-def allreduce_gradients(parameters, bucket_bytes=64 << 20, average=True):
+def allreduce_gradients(parameters, bucket_bytes=64 << 20, average=True, n_local=None):
     """Data-parallel gradient reduction for the one-process-per-GPU trainer: the ``.grad`` tensors are packed
     into a few large flat buckets (the MNIST model's 5.98 M fp32 gradients = 24 MB are ONE bucket) and all-reduced over
     RCCL / xGMI -- the point-to-point links favour few, large collectives over a per-parameter loop.  ``nn.DataParallel``
     in the reference does the equivalent reduce-to-device-0 inside its backward (``wrapper.py:52-68``).  In place; a
-    parameter without a gradient on this rank contributes zeros (every rank must call with the same parameter list)."""
+    parameter without a gradient on this rank contributes zeros (every rank must call with the same parameter list).
+    ``n_local`` = this rank's sample count: gradients are then combined as sum_r n_r g_r / sum_r n_r, the gradient of the
+    mean over the GLOBAL batch (``non_square_helpers.py:120`` on the gathered elbos) even when the shards are unequal."""
     params = [p for p in parameters if p.requires_grad]
     if not params:
         return 0
     world = dist.get_world_size() if _active() else 1
+    weight, total = 1.0, float(world)
+    if n_local is not None and average and _active():
+        cnt = torch.tensor([float(n_local)], dtype=torch.float64, device=params[0].device)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        weight, total = float(n_local), float(cnt.item())
     buckets, cur, size = [], [], 0
     for p in params:
         n = p.numel() * 4
@@ -66,9 +73,11 @@ def allreduce_gradients(parameters, bucket_bytes=64 << 20, average=True):
     for group in buckets:
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in group])
         if _active():
+            if weight != 1.0:
+                flat *= weight
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             if average:
-                flat /= world
+                flat /= total
         off = 0
         for p in group:
             n = p.numel()

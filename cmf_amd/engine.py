@@ -155,11 +155,18 @@ class _PackCache:
 
     def __init__(self):
         self._store = {}
+        self.generation = 0
+
+    def invalidate(self):
+        """Every cached pack is stale from now on.  Called by writers that change parameter VALUES without touching the
+        tensors' version counters: ``FlatOptimizer.step`` updates the flat buffer with a raw HIP kernel, and a parameter
+        whose ``.data`` is a view of that buffer keeps ``_version`` 0 whatever happens to the storage."""
+        self.generation += 1
 
     def get(self, weight, taps, transpose=False, bf16x3=False):
         import weakref
         key = (id(weight), bool(transpose), bool(bf16x3))
-        ver = (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape))
+        ver = (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape), self.generation)
         hit = self._store.get(key)
         if hit is not None and hit[0]() is weight and hit[1] == ver:
             return hit[2]
@@ -432,10 +439,18 @@ def gram_cholesky(T, d, max_attempts=6, eps0=1e-6):
         launch()
     else:                                          # 2 D d^2 (+ d^3/3) FLOP and (D NC + d^2 + 3) 4 B per sample
         TIMER.wrap("gram_cholesky", T.B * (2.0 * T.N * d * d + d ** 3 / 3.0), 4.0 * T.B * (T.N * T.nc + d * d + 3), launch)
-    for a in range(1, max_attempts):
-        _lib.check(lib.cmf_cholesky_retry(_p(r.jtj), d, T.B, a, eps0, _p(r.logdet), _p(r.l1_diag), _p(r.info), _p(r.fail),
-                                          _stream()), "cmf_cholesky_retry")
+    cholesky_retries(r, d, max_attempts, eps0)
     return r
+
+
+def cholesky_retries(r, d, max_attempts=6, eps0=1e-6):
+    """Enqueue the whole-batch jitter retries 1 .. max_attempts-1 behind a factorisation (non_square.py:280-288): retry ``a``
+    exits at once unless ``fail[a-1]`` is set, else adds eps0 * 10^(a-1) to every sample's diagonal IN PLACE and factorises again."""
+    lib = _lib.load()
+    B = r.jtj.shape[0]
+    for a in range(1, max_attempts):
+        _lib.check(lib.cmf_cholesky_retry(_p(r.jtj), d, B, a, eps0, _p(r.logdet), _p(r.l1_diag), _p(r.info), _p(r.fail),
+                                          _stream()), "cmf_cholesky_retry")
 
 
 def gram_backward(T, jtj, g_logdet=None, g_l1off=None, g_l1diag=None):
@@ -473,6 +488,25 @@ def hutch_cg(jtj, eps, max_iter, tol, min_iter=None):
     _lib.check(_lib.load().cmf_hutch_cg(_p(jtj), _p(eps.contiguous()), d, S, B, int(max_iter), int(min_iter), float(tol),
                                         _p(u), _p(w), _p(val), _p(iters), _stream()), "cmf_hutch_cg")
     return val, u, w, iters
+
+
+def hutch_metric(w):
+    """(l1_off, l1_diag) of the Hutchinson product W = (J^T J) eps, (B, d, S) with S == d (non_square.py:87-100 on :253-258)."""
+    B, d, S = w.shape
+    off = torch.empty(B, dtype=torch.float32, device=w.device)
+    diag = torch.empty(B, dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().cmf_hutch_metric(_p(w.contiguous()), d, S, B, _p(off), _p(diag), _stream()), "cmf_hutch_metric")
+    return off, diag
+
+
+def hutch_cotangent(u, eps, w, g_val=None, g_off=None, g_diag=None):
+    """d objective / d (J^T J) as an explicit (B, d, d) matrix for the train-mode Hutchinson objective (u detached)."""
+    B, d, S = eps.shape
+    M = torch.empty(B, d, d, dtype=torch.float32, device=eps.device)
+    gs = [None if g is None else g.to(torch.float32).contiguous() for g in (g_val, g_off, g_diag)]
+    _lib.check(_lib.load().cmf_hutch_cotangent(_p(u.contiguous()), _p(eps.contiguous()), _p(w.contiguous()), d, S, B,
+                                               *[None if g is None else _p(g) for g in gs], _p(M), _stream()), "cmf_hutch_cotangent")
+    return M
 
 
 def prehead(x, noise, a, c, logit):

@@ -19,6 +19,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from . import engine as _engine
 
 KINDS = {"sgd": 0, "adam": 1, "adamax": 2}
 _SECOND = {"adam": "exp_avg_sq", "adamax": "exp_inf"}
@@ -60,7 +61,9 @@ class FlatOptimizer(torch.optim.Optimizer):
             n += (p.numel() + 3) // 4 * 4
         self.n = n
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        # the gradient bucket carries 4 trailing floats: slot 0 = this rank's sample count for the weighted data-parallel mean
+        self._bucket = torch.zeros(n + 4, dtype=torch.float32, device=dev)
+        self.grad = self._bucket[:n]
         for p, o in zip(self.params, self.offsets):
             view = self.flat[o:o + p.numel()].view(p.shape)
             view.copy_(p.data)
@@ -94,19 +97,34 @@ class FlatOptimizer(torch.optim.Optimizer):
         _lib.check(lib.cmf_optimizer_step(KINDS[self.opt], _p(self.flat), _p(self.grad), _p(self.m), _p(self.v), self.n,
                                           self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
                                           _p(sq), float(self.max_grad_norm or 0.), _stream()), "cmf_optimizer_step")
+        # the kernel wrote new VALUES into storage the parameters view: no tensor version counter moved, so the packed
+        # (kernel-layout) weight copies keyed on ``_version`` would all be stale hits
+        _engine.PACKS.invalidate()
 
     def grad_norm(self):
         """Global gradient 2-norm as a device scalar (what ``clip_grad_norm_`` returns)."""
+        self._check_views()
         _lib.check(_lib.load().cmf_grad_sqnorm(_p(self.grad), self.n, _p(self._ws), _p(self._sq), _stream()), "cmf_grad_sqnorm")
         return self._sq.sqrt()[0]
 
-    def allreduce_flat(self, average=True):
-        """Data-parallel gradient reduction: the flat gradient buffer IS the bucket."""
+    def allreduce_flat(self, average=True, n_local=None):
+        """Data-parallel gradient reduction: the flat gradient buffer IS the bucket.
+        ``n_local`` = this rank's sample count: the result is then the gradient of the GLOBAL batch mean,
+        sum_r n_r g_r / sum_r n_r -- what the reference's DataParallel gather + ``.mean()`` differentiates
+        (wrapper.py:52-54, non_square_helpers.py:120) -- also when the shards are unequal.  Without it: plain mean over ranks."""
         import torch.distributed as dist
+        self._check_views()                                   # autograd may have replaced p.grad: fold it back BEFORE reducing
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
-            if average:
-                self.grad.mul_(1.0 / dist.get_world_size())
+            if n_local is not None and average:
+                self.grad.mul_(float(n_local))
+                self._bucket[self.n:].zero_()
+                self._bucket[self.n] = float(n_local)
+                dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
+                self.grad.div_(self._bucket[self.n])
+            else:
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+                if average:
+                    self.grad.mul_(1.0 / dist.get_world_size())
 
     def _check_views(self):
         # autograd may REPLACE p.grad (e.g. after `p.grad = None`); fold such gradients back into the flat buffer

@@ -18,7 +18,7 @@ import zlib
 import numpy as np
 import torch
 
-__all__ = ["fill_state_dict", "recipe_tensor"]
+__all__ = ["fill_state_dict", "recipe_tensor", "apply_gain"]
 
 
 def _rng(key, seed):
@@ -58,11 +58,23 @@ def recipe_tensor(key, shape, dtype, seed, sibling_shapes=None):
     raise KeyError(f"recipe has no rule for state-dict key {key!r} of shape {shape}")
 
 
-def fill_state_dict(state_dict, seed=0):
-    """Return a new state dict with the same keys/shapes/dtypes filled by the recipe."""
+def apply_gain(key, t, gain):
+    """``gain`` = {leaf name: multiplier} for floating-point recipe tensors -- the knob the ill-conditioned parity fixtures
+    turn: ``{"weights": 3.0}`` triples every ScaledTanh scale (the bound of an image coupler's log-scale),
+    ``{"weight": 1.5}`` every conv / linear weight.  Only the low-dimensional prior flows (keys holding no image / tabular
+    coupler above the base) are left alone when the leaf is given as ``"flow.weight"``-style entries; plain leaves match all."""
+    if not gain or t is None or not t.is_floating_point():
+        return t
+    leaf = key.rsplit(".", 1)[-1]
+    g = gain.get(leaf)
+    return t if g is None else t * float(g)
+
+
+def fill_state_dict(state_dict, seed=0, gain=None):
+    """Return a new state dict with the same keys/shapes/dtypes filled by the recipe (``gain``: see ``apply_gain``)."""
     shapes = {k: tuple(v.shape) for k, v in state_dict.items()}
     out = {}
     for k, v in state_dict.items():
-        t = recipe_tensor(k, v.shape, v.dtype, seed, shapes)
+        t = apply_gain(k, recipe_tensor(k, v.shape, v.dtype, seed, shapes), gain)
         out[k] = v.detach().clone() if t is None else t.reshape(v.shape).to(v.dtype)
     return out

@@ -25,12 +25,12 @@ def train_batch(density, x, epoch, train_metrics, optimizers, lr_schedulers=None
     metrics = train_metrics(density, x, epoch)
     metrics["loss"].backward()
     if isinstance(opt, FlatOptimizer):
-        opt.allreduce_flat()
+        opt.allreduce_flat(n_local=x.shape[0])
         if max_grad_norm is not None:
             opt.max_grad_norm = max_grad_norm
     else:
         params = [p for group in opt.param_groups for p in group["params"]]
-        allreduce_gradients(params)
+        allreduce_gradients(params, n_local=x.shape[0])
         if max_grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(density.parameters(), max_grad_norm)
     opt.step()

@@ -11,7 +11,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous;
  *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
  *     CMF_E* code for invalid arguments.  Nothing throws across this boundary;
- *   - no global mutable state: every call is re-entrant (one Python thread per device is fine).
+ *   - every call is re-entrant and uses the calling thread's CURRENT device (one Python thread per GPU in one process is
+ *     fine).  The only mutable global is a lock-free per-(device, kernel) memo of launch attributes already set
+ *     (csrc/runtime.hip: dynamic-LDS limit, CU count); entries are idempotent and never removed.
  *
  * Data layouts
  *   primal tensor   P(b, r)        = p[b*p_b + r*p_r]                  (B, N) row-major, = torch layout
@@ -257,10 +259,21 @@ int cmf_elbo_combine(const float* low, const float* logdet, const float* rec, co
  * cmf_gram_cholesky (see hutch_cg.hip for why the explicit form is the cheaper one on this hardware):
  *   w(b,:,s) = G(b) eps(b,:,s);  u = CG(G, eps) with x0 = 0, unit-normalised right-hand sides, at least
  *   min_iter and at most max_iter iterations, stopping a sample when the mean over its S probes of the
- *   relative residual 2-norm drops below tol;  val[b] = mean_s sum_k u*w.   eps, u, w: [B][d][S]; S <= 16.
+ *   relative residual 2-norm drops below tol;  val[b] = mean_s sum_k u*w.   eps, u, w: [B][d][S]; S <= 128
+ *   (probes beyond 16 run in chunks of 16 with the stopping rule applied per chunk; iters[b] = the slowest chunk).
  * The reference's solver (gpytorch linear_cg @ fc2053b) is un-vendored: CG iterates are parity-unpinned. */
 int cmf_hutch_cg(const float* jtj, const float* eps, int d, int S, int B, int max_iter, int min_iter, float tol,
                  float* u, float* w, float* val, int* iters, void* stream);
+/* Metric term on the Hutchinson product W = (J^T J) eps, [B][d][S] with S == d -- the third return value of
+ * non_square.py:253-258 fed to :87-100:  l1_diag[b] = sum_k |W_kk|,  l1_off[b] = sum_{i != j} |W_ij|
+ * (the reference's masked_select(~eye).view(B, d(d-1)) exists only for S == d).  Either output may be NULL. */
+int cmf_hutch_metric(const float* w, int d, int S, int B, float* l1_off, float* l1_diag, void* stream);
+/* Cotangent of the Gram matrix for the train-mode Hutchinson objective, u detached (non_square.py:236-247):
+ *   M(b) = g_val[b]/S sum_s u_s eps_s^T + sum_s (g_off[b] [i != s] + g_diag[b] [i == s]) sign(W_is) e_i eps_s^T,
+ * [B][d][d]; feed it to cmf_gram_backward_matrix (dJ = J (M + M^T)).  g_val / g_off / g_diag: [B] or NULL; the metric
+ * terms need w and S == d. */
+int cmf_hutch_cotangent(const float* u, const float* eps, const float* w, int d, int S, int B, const float* g_val,
+                        const float* g_off, const float* g_diag, float* M, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Non-convolution pieces of the coupler networks' primal backward.

@@ -412,6 +412,50 @@ def encode(sd, flow_ops, base, prior_ops, x):
     return z_low, lj, u
 
 
+def nested_elbos(sd, ops, y):
+    """The "elbo" entry at every level of the nested ``prior-dict`` the head returns (non_square.py:126-129), outermost
+    first: BijectionDensity = deeper elbo + log-jac (exact.py:23-30), SplitDensity = density_1's + the Gaussian log-prob of
+    the dropped half (split.py:15-24), tail = its prior's (non_square.py:381-395), Gaussian = log-prob (gaussian.py:65-74).
+    ``y`` = the head's input.  Returns a list of (B, 1) tensors, one per level."""
+    pre, head, flow_ops, base, prior_ops = split_ops(ops)
+    h, contrib = y, []
+    for op in flow_ops:
+        k = op["kind"]
+        if k == "acl":
+            h, lj = acl_x_to_z(sd, op, h)
+            contrib.append(lj)
+        elif k == "flatten":
+            h = h.flatten(1)
+            contrib.append(torch.zeros_like(lj) if contrib else h.new_zeros(h.shape[0], 1))
+        elif k == "squeeze":
+            h = squeeze_x_to_z(h, op["factor"])
+            contrib.append(h.new_zeros(h.shape[0], 1))
+        elif k == "split":
+            h, h2 = torch.chunk(h, 2, dim=1)
+            contrib.append(gaussian_log_prob(h2))
+    u = tail_gather(sd, base, h)
+    contrib.append(u.new_zeros(u.shape[0], 1))             # the tail forwards its prior's elbo
+    for op in prior_ops:
+        k = op["kind"]
+        if k == "flatten":
+            u = u.flatten(1)
+            contrib.append(u.new_zeros(u.shape[0], 1))
+        elif k == "acl":
+            u, lj = acl_x_to_z(sd, op, u)
+            contrib.append(lj)
+        elif k == "affine":
+            ls, sh = sd[op["prefix"] + "log_scale"], sd[op["prefix"] + "shift"]
+            u = u * torch.exp(ls) + sh
+            contrib.append(ls.sum().expand(u.shape[0], 1))
+        elif k == "gaussian":
+            contrib.append(gaussian_log_prob(u))
+    out, acc = [], 0
+    for c in reversed(contrib):
+        acc = acc + c
+        out.append(acc)
+    return out[::-1]
+
+
 # --------------------------------------------------------------------------------------
 # decode + Jacobian assembly
 # --------------------------------------------------------------------------------------

@@ -54,7 +54,13 @@ def _import_reference():
     return get_density, get_config, get_schema, expand_grid
 
 
-# name -> (dataset, reference-config overrides, batch, extras)
+_MM = {"g_hidden_channels": [8] * 2, "latent_dimension": 4, "log_jacobian_method": "cholesky"}
+_MC = {"g_hidden_channels": [8] * 2, "latent_dimension": 6, "log_jacobian_method": "cholesky"}
+
+# name -> (dataset, reference-config overrides, batch[, options])
+#   options: "gain" = recipe gain (cmf_amd.recipe.apply_gain) raising the conditioning of J^T J: the default recipe (PyTorch's
+#   default init) gives cond <= 6; trained flows are far less tame, so each small model also comes at cond ~ 1e2 and ~ 1e3
+#   (SURVEY 8d); "full" = full-size model: only (B, 1) outputs and J^T J are stored.
 CASES = {
     "c1_sphere": ("sphere", {"latent_dimension": 3}, 32),
     "c1_sphere_d2": ("sphere", {"latent_dimension": 2}, 16),
@@ -64,7 +70,18 @@ CASES = {
     "mini_cifar": ("cifar10", {"g_hidden_channels": [8] * 2, "latent_dimension": 6, "log_jacobian_method": "cholesky"}, 2),
     "mini_mnist_small": ("mnist", {"g_hidden_channels": [8] * 1, "latent_dimension": 5, "smaller_realnvp": True,
                                    "log_jacobian_method": "cholesky"}, 2),
-    "c3_mnist_full": ("mnist", {"latent_dimension": 64, "log_jacobian_method": "cholesky"}, 2),
+    "c3_mnist_full": ("mnist", {"latent_dimension": 64, "log_jacobian_method": "cholesky"}, 2, {"full": True}),
+    "mini_mnist_cond1e2": ("mnist", _MM, 3, {"gain": {"weights": 3.7}}),
+    "mini_mnist_cond1e3": ("mnist", _MM, 3, {"gain": {"weights": 4.15}}),
+    "mini_cifar_cond1e2": ("cifar10", _MC, 2, {"gain": {"weights": 2.5}}),
+    "mini_cifar_cond1e3": ("cifar10", _MC, 2, {"gain": {"weights": 3.2}}),
+    "c2b_hepmass_cond1e2": ("hepmass", {}, 16, {"gain": {"weight": 1.4}}),
+    "c2b_hepmass_cond1e3": ("hepmass", {}, 16, {"gain": {"weight": 1.6}}),
+    "c2b_hepmass_cond4e3": ("hepmass", {}, 16, {"gain": {"weight": 1.7}}),
+    "c3_mnist_full_cond": ("mnist", {"latent_dimension": 64, "log_jacobian_method": "cholesky"}, 2,
+                           {"full": True, "gain": {"weights": 2.3}}),
+    "c5_cifar_full": ("cifar10", {"latent_dimension": 128, "log_jacobian_method": "cholesky", "hutchinson_samples": 4}, 2,
+                      {"full": True}),
 }
 
 ELBO_COMBOS = [  # (likelihood_wt, metric_wt, add_reconstruction, add_offdiag, add_diag)   SURVEY 8(a) a17
@@ -93,6 +110,46 @@ def find_head(density):
     return m
 
 
+def jitter_fixture(get_density, ref_get_config, ref_get_schema, expand_grid):
+    """The reference's whole-batch jitter loop (non_square.py:262-296) on Jacobians that make it retry.
+
+    A flow's J has full column rank analytically (every layer is a bijection, the tail scatter is injective), so J^T J is
+    singular only through rounding -- and whether a rounding-level pivot comes out <= 0 differs between any two fp32
+    implementations.  A retry that BOTH sides take deterministically needs exact arithmetic: columns 0 and 1 of sample 1 are
+    the same single non-zero entry 2^k, so G_00 = G_01 = G_11 = 4^k exactly, sqrt / divide / square are exact and the second
+    pivot is exactly 0.  k = -7: the first jitter (1e-6) cures it (2 attempts).  k = 5 (G = 1024, ulp 1.2e-4): 1e-6 and 1e-5
+    are absorbed by rounding, 1e-4 is not (4 attempts).  Sample 0 is a well-conditioned random Jacobian that receives the same
+    whole-batch jitter.  The reference head runs its own loop; only its Jacobian provider is replaced by these matrices."""
+    import contextlib
+    import io
+    import re
+    from cmf_amd import schemas as my_schemas
+    cfg = expand_grid({**ref_get_config("sphere", "non-square", False), "latent_dimension": 3})[0]
+    head = find_head(get_density(ref_get_schema(cfg), torch.zeros(4, 3)))
+    head.eval()
+    gen = torch.Generator().manual_seed(77)
+    out = {}
+    for tag, k, D, d in (("a", -7, 8, 4), ("b", 5, 8, 4)):
+        J = torch.zeros(3, D, d)
+        J[0] = torch.randn(D, d, generator=gen) * (2.0 ** k)
+        J[1, 0, 0] = J[1, 0, 1] = 2.0 ** k
+        J[1, 1:d - 1, 2:] = torch.eye(d - 2) * (2.0 ** k)
+        J[2] = torch.randn(D, d, generator=gen) * (2.0 ** k)
+        jtj = torch.bmm(J.transpose(1, 2), J)
+        head._get_full_jac_transpose_jac = lambda latent, cg, _j=jtj: (_j.clone(), torch.zeros(latent.shape[0], 3))
+        buf = io.StringIO()
+        with torch.no_grad(), contextlib.redirect_stdout(buf):
+            logdet, _, jittered = head._exact_log_det_jac_and_reconstruction(torch.zeros(3, d))
+        m = re.search(r"(\d+) attempts needed", buf.getvalue())
+        attempts = int(m.group(1)) if m else 1
+        out.update({f"J_{tag}": J.numpy(), f"jtj_{tag}": jtj.numpy(), f"logdet_{tag}": logdet.numpy(),
+                    f"jittered_{tag}": jittered.numpy(), f"attempts_{tag}": np.array(attempts)})
+        print(f"jitter_retry[{tag}]: k={k} attempts={attempts} logdet={logdet.ravel().tolist()}")
+    del head._get_full_jac_transpose_jac
+    out["meta"] = np.array(json.dumps({"what": "reference jitter loop on crafted Jacobians", "cases": ["a", "b"]}))
+    np.savez_compressed(os.path.join(GOLDEN, "jitter_retry.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -102,9 +159,13 @@ def main():
     from cmf_amd.recipe import fill_state_dict
     from cmf_amd import schemas as my_schemas
 
-    for name, (dataset, over, B) in CASES.items():
+    if not args.only or args.only == "jitter_retry":
+        jitter_fixture(get_density, ref_get_config, ref_get_schema, expand_grid)
+    for name, (dataset, over, B, *opt) in CASES.items():
         if args.only and args.only != name:
             continue
+        opt = opt[0] if opt else {}
+        gain, full = opt.get("gain"), opt.get("full", False)
         torch.manual_seed(0)
         cfg = expand_grid({**ref_get_config(dataset, "non-square", False), **over})[0]
         schema = ref_get_schema(cfg)
@@ -116,7 +177,7 @@ def main():
         gen = torch.Generator().manual_seed(1234)
         x = synth_input(dataset, shape, B, gen)
         density = get_density(schema, x)
-        sd = fill_state_dict(density.state_dict(), seed=0)
+        sd = fill_state_dict(density.state_dict(), seed=0, gain=gain)
         # Checkerboard masks with C>1 are stride-0 expanded buffers in the reference (acl.py:73) and
         # cannot be copied into; they are structural (the recipe leaves them alone), so skip them.
         res = density.load_state_dict({k: v for k, v in sd.items() if not k.endswith("bijection.mask")}, strict=False)
@@ -150,12 +211,19 @@ def main():
                 y, pre_lj = res["z"], pre_lj + res["log-jac"]
                 m = m.prior
             prior_dict = head.prior.elbo(y)
+            # the nested "prior-dict" the head returns (non_square.py:126-129): per level its keys and its (B, 1) elbo
+            levels, node = [], prior_dict
+            while isinstance(node, dict):
+                levels.append((sorted(node.keys()), node["elbo"].numpy().copy()))
+                node = node.get("prior-dict")
+            out["nested_elbo"] = np.stack([e for _, e in levels])
+            nested_keys = [k for k, _ in levels]
             z_low, low_elbo, earliest = head._traverse_backward(y, prior_dict)
             logdet, x_hat, jtj = head._exact_log_det_jac_and_reconstruction(z_low)
             out.update(head_input=y.numpy(), prehead_logjac=pre_lj.numpy(), z_low=z_low.numpy(),
                        low_dim_elbo=low_elbo.numpy(), earliest_latent=earliest.numpy(),
                        logdet=logdet.numpy(), x_hat=x_hat.numpy(), jtj=jtj.numpy())
-            if name != "c3_mnist_full":
+            if not full:
                 cols = []
                 for i in range(z_low.shape[1]):
                     v = torch.zeros_like(z_low); v[:, i] = 1
@@ -173,7 +241,7 @@ def main():
             out["fixed_sample"] = density.fixed_sample(zn).numpy()
             out["fixed_sample_default"] = density.fixed_sample()[:4].numpy()
         # Hutchinson building block J^T J eps through the reference's jvp + autograd vjp
-        if name != "c3_mnist_full":
+        if not full:
             S = 3
             eps = torch.randn(B, cfg["latent_dimension"], S, generator=gen)
             rep = z_low.repeat_interleave(S, dim=0)
@@ -194,7 +262,7 @@ def main():
                     out["elbo_0_fp64"] = inner64.elbo(xin, add_offdiagonal_metric_reg=True)["elbo"].numpy()
             finally:
                 torch.set_default_dtype(torch.float32)
-        meta = {"dataset": dataset, "overrides": over, "batch": B, "recipe_seed": 0,
+        meta = {"dataset": dataset, "overrides": over, "batch": B, "recipe_seed": 0, "recipe_gain": gain, "nested_keys": nested_keys,
                 "state_dict": {k: [list(v.shape), str(v.dtype)] for k, v in sd.items()},
                 "elbo_combos": ELBO_COMBOS, "cond_jtj_max": float(torch.linalg.cond(jtj).max())}
         out["meta"] = np.array(json.dumps(meta))

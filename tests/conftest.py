@@ -28,7 +28,7 @@ def golden_model(meta, dtype=torch.float32):
     """Rebuild (schema, x_shape, oracle ops, recipe state dict) for a fixture without the reference:
     the state-dict key/shape list is stored in the fixture, values come from the recipe."""
     from cmf_amd import schemas
-    from cmf_amd.recipe import recipe_tensor
+    from cmf_amd.recipe import apply_gain, recipe_tensor
     from oracle import cmf_oracle as O
 
     cfg = schemas.get_config(meta["dataset"], **meta["overrides"])
@@ -39,7 +39,7 @@ def golden_model(meta, dtype=torch.float32):
     sd = {}
     for k, (shape, dt) in meta["state_dict"].items():
         tdt = getattr(torch, dt.replace("torch.", ""))
-        t = recipe_tensor(k, shape, tdt, meta["recipe_seed"], shapes)
+        t = apply_gain(k, recipe_tensor(k, shape, tdt, meta["recipe_seed"], shapes), meta.get("recipe_gain"))
         if t is None:
             t = structural_buffer(k, tuple(shape), ops, tdt)
         if t.is_floating_point():
@@ -68,6 +68,15 @@ def structural_buffer(key, shape, ops, dtype):
     raise KeyError(key)
 
 
+#: fixture families (oracle/make_golden.py CASES)
+SMALL = ["c1_sphere", "c1_sphere_d2", "c2a_power", "c2b_hepmass", "mini_mnist", "mini_cifar", "mini_mnist_small"]
+#: the small models with the recipe's gain raised until the REFERENCE reports cond(J^T J) ~ 1e2 ... 4e3
+COND = ["mini_mnist_cond1e2", "mini_mnist_cond1e3", "mini_cifar_cond1e2", "mini_cifar_cond1e3", "c2b_hepmass_cond1e2",
+        "c2b_hepmass_cond1e3", "c2b_hepmass_cond4e3"]
+#: full-size models: (B, 1) outputs and J^T J only
+FULL = ["c3_mnist_full", "c3_mnist_full_cond", "c5_cifar_full"]
+
+
 @pytest.fixture(scope="session")
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "jitter_retry.npz")

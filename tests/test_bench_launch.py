@@ -1,0 +1,42 @@
+"""bench.py as a launcher (CPU): the parent process that starts the per-GPU ranks must never touch the GPU -- it does not even
+import torch -- and must turn a failing rank into a non-zero exit code."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parent_does_not_import_torch_and_reports_failing_ranks(tmp_path):
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import sys, runpy\n"
+        f"sys.argv = [{os.path.join(ROOT, 'bench.py')!r}, '--gpus', '2', '--backend', 'gloo', '--share-gpu', '--batch', '4']\n"
+        "try:\n"
+        f"    runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')\n"
+        "except SystemExit as e:\n"
+        "    print('PARENT', int(e.code or 0), 'torch' in sys.modules)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(probe)], capture_output=True, text=True, env=env, timeout=300)
+    last = [l for l in r.stdout.splitlines() if l.startswith("PARENT")][-1].split()
+    # there is no GPU here: both ranks fail in torch.cuda.set_device -> the parent must exit non-zero, without torch loaded
+    assert int(last[1]) != 0 and last[2] == "False", r.stdout + r.stderr[-2000:]
+    assert "rank exit codes" in r.stderr
+
+
+def test_rank_environment_is_honoured(monkeypatch):
+    """Under torch.distributed.run the environment carries WORLD_SIZE: bench.py must then BE a rank, not spawn."""
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse_args(["--gpus", "4", "--config", "c2a"])
+    assert args.gpus == 4 and args.batch == 4096 and args.steps == 20 and args.cpu_batch == 4096
+    args = bench.parse_args([])
+    assert (args.gpus, args.steps, args.warmup, args.batch, args.config) == (1, 3, 1, 512, "c3")
+    called = {}
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setattr(bench, "spawn_ranks", lambda *a: called.setdefault("spawn", True))
+    monkeypatch.setattr(bench, "run_rank", lambda a: called.setdefault("rank", a.gpus))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    bench.main()
+    assert called == {"rank": 4}

@@ -122,3 +122,44 @@ def test_allreduce_gradients_matches_full_batch():
         for got, w in zip(res[r][2], want):
             assert torch.allclose(torch.from_numpy(got), w, rtol=1e-6, atol=1e-7)
 
+
+
+def _weighted_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cmf_amd.distributed import allreduce_gradients, shard_batch
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 1))
+        x = torch.arange(35, dtype=torch.float32).reshape(7, 5) / 10        # 7 samples over 2 ranks: shards of 4 and 3
+        mine = shard_batch(x)
+        (-net(mine).mean()).backward()                                       # the per-shard mean loss of the training closure
+        allreduce_gradients(list(net.parameters()), n_local=mine.shape[0])
+        q.put((rank, mine.shape[0], [p.grad.numpy().copy() for p in net.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weighted_gradient_mean_equals_the_global_batch_mean():
+    """Unequal shards (7 samples on 2 ranks): sum_r n_r g_r / sum_r n_r is the gradient of the mean over the GATHERED batch,
+    which is what the reference's DataParallel + ``elbo.mean()`` differentiates (wrapper.py:52-54, non_square_helpers.py:120);
+    the plain mean over ranks is not."""
+    world, port = 2, 29561
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_weighted_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == [4, 3]
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 1))
+    x = torch.arange(35, dtype=torch.float32).reshape(7, 5) / 10
+    (-net(x).mean()).backward()
+    for r in range(2):
+        for got, p in zip(res[r][2], net.parameters()):
+            assert torch.allclose(torch.from_numpy(got), p.grad, rtol=1e-5, atol=1e-7)

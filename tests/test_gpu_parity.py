@@ -12,8 +12,8 @@ from conftest import load_golden, golden_model
 
 pytestmark = pytest.mark.gpu
 
-SMALL = ["c1_sphere", "c1_sphere_d2", "c2a_power", "c2b_hepmass", "mini_mnist", "mini_cifar", "mini_mnist_small"]
-ALL = SMALL + ["c3_mnist_full"]
+from conftest import COND, FULL, SMALL
+ALL = SMALL + COND + FULL
 
 
 def rel(a, b, floor=1e-9):
@@ -29,7 +29,7 @@ def build(name):
     g, meta = load_golden(name)
     cfg = cmf_amd.get_config(meta["dataset"], **meta["overrides"])
     dens = cmf_amd.get_density(cmf_amd.get_schema(cfg), g["x"])
-    dens.load_state_dict(fill_state_dict(dens.state_dict(), seed=meta["recipe_seed"]), strict=True)
+    dens.load_state_dict(fill_state_dict(dens.state_dict(), seed=meta["recipe_seed"], gain=meta.get("recipe_gain")), strict=True)
     dens = dens.cuda().eval()
     return g, meta, cfg, dens
 

@@ -1,0 +1,353 @@
+"""Round-2 GPU tests: ill-conditioned and retrying reference vectors, training robustness (stale weight packs, jitter under
+training, the metric term on the Hutchinson product), the nested prior-dict, the self-launching benchmark.  Every call goes
+through the C ABI of libcmf_amd.so."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import COND, ROOT, golden_model, load_golden
+from test_gpu_parity import build, find_head, inner, rel
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference's jitter loop
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("tag,attempts", [("a", 2), ("b", 4)])
+def test_cholesky_retries_match_the_reference_loop(tag, attempts):
+    """jitter_retry.npz: Jacobians on which the REFERENCE's loop (non_square.py:262-296) takes 2 and 4 attempts (exactly
+    singular in exact arithmetic; the second case has jitters absorbed by fp32 rounding).  The fused Gram + Cholesky kernel
+    and its device-side retry chain take the same number of attempts, jitter every sample, and return the reference's
+    log-dets and jittered matrices."""
+    from cmf_amd import engine as E
+    g, _ = load_golden("jitter_retry")
+    J = g[f"J_{tag}"].cuda()
+    B, D, d = J.shape
+    T = E.Tangent.from_dense(J, E.ceil16(d), "panel")
+    r = E.gram_cholesky(T, d)
+    fail = r.fail.tolist()
+    n = 1
+    while fail[n - 1]:
+        n += 1
+    assert n == attempts == int(g[f"attempts_{tag}"])
+    assert rel(r.jtj, g[f"jittered_{tag}"]) < 1e-6                     # the jitter lands on EVERY sample's diagonal
+    want = g[f"logdet_{tag}"].flatten()
+    got = r.logdet.cpu()
+    for b in (0, 2):                                                   # well-conditioned samples
+        assert abs(float(got[b] - want[b])) / abs(float(want[b])) < 1e-4
+    if tag == "a":                                                     # singular sample: pivot ~ 2 eps, resolved to ~4e-6
+        assert abs(float(got[1] - want[1])) / abs(float(want[1])) < 1e-4
+    else:                                                              # pivot = a few ulp(1024): rounding decides its value
+        assert abs(float(got[1] - want[1])) < 1.5
+    assert rel(r.l1_diag, torch.diagonal(g[f"jittered_{tag}"], dim1=1, dim2=2).abs().sum(1)) < 1e-5
+
+
+def _oracle_objective(sd64, ops, x, jitter, kw):
+    """-elbo.mean() through the float64 oracle with ``jitter`` added to the diagonal of J^T J before the factorisation --
+    what the reference differentiates when its loop retries (the jitter is a constant, non_square.py:284-296)."""
+    from oracle import cmf_oracle as O
+    pre, head, flow_ops, base, prior_ops = O.split_ops(ops)
+    y, lj_pre = O.prehead(pre, x, torch.zeros_like(x))
+    z_low, low_elbo, _ = O.encode(sd64, flow_ops, base, prior_ops, y)
+    jtj, xh, J = O.jtj_batched(sd64, flow_ops, base, z_low)
+    jtj = jtj + jitter * torch.eye(jtj.shape[1], dtype=jtj.dtype)
+    logdet = 2 * torch.log(torch.diagonal(torch.linalg.cholesky(jtj), dim1=-2, dim2=-1)).sum(1, keepdim=True)
+    l1 = O.metric_l1(jtj, kw.get("add_diagonal_metric_reg", False)) if (kw.get("add_diagonal_metric_reg") or
+                                                                          kw.get("add_offdiagonal_metric_reg")) else 0
+    recon = ((xh - y).flatten(1) ** 2).sum(-1, keepdim=True)
+    elbo = (low_elbo - logdet / 2) - head["regularization_param"] * recon - l1 + lj_pre
+    return -elbo.mean(), y, lj_pre
+
+
+@pytest.mark.parametrize("kw", [dict(add_offdiagonal_metric_reg=True), dict(add_diagonal_metric_reg=True)])
+def test_training_differentiates_through_the_jittered_matrix(kw, monkeypatch):
+    """A batch whose first factorisation fails trains on (the reference calls its loop with create_graph=self.training): the
+    gradient flows through J^T J + eps I.  The failure is forced (flag raised after attempt 0) with a LARGE eps0 so that the
+    jitter visibly changes the gradient: HIP gradients = autograd through the float64 oracle with the same jitter, and differ
+    from the unjittered gradients."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build("mini_mnist")
+    _, schema, x_shape, ops, sd = golden_model(meta, dtype=torch.float64)
+    head = find_head(dens)
+    named = dict(dens.named_parameters())
+    keys = [k for k, v in sd.items() if v.is_floating_point() and k in named]
+    x = g["x"][:3].double()
+    eps0 = 0.05
+    orig = E.gram_cholesky
+
+    def forced(T, d, max_attempts=6, eps0_=1e-6):
+        r = orig(T, d, 1)
+        r.fail[0] = 1
+        E.cholesky_retries(r, d, max_attempts, eps0)
+        return r
+
+    grads = {}
+    for jitter in (eps0, 0.0):
+        sd64 = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+        loss, y, lj_pre = _oracle_objective(sd64, ops, x, jitter, kw)
+        grads[jitter] = (loss.detach(), torch.autograd.grad(loss, [sd64[k] for k in keys], allow_unused=True))
+    monkeypatch.setattr(E, "gram_cholesky", forced)
+    head.check_cholesky = "lazy"
+    pre = lj_pre.float().reshape(-1).cuda()
+    loss, elbo, got = head.loss_and_gradients(y.float().cuda(), pre_logjac=pre, **kw)
+    assert head.last_gram.fail.tolist()[:2] == [1, 0]                   # exactly one retry ran
+    want_loss, want = grads[eps0]
+    assert rel(loss, want_loss) < 1e-5
+    moved = 0
+    for k, w, w0 in zip(keys, want, grads[0.0][1]):
+        if w is None or float(w.abs().max()) == 0:
+            continue
+        assert rel(got[named[k]], w.reshape(named[k].shape)) < 1e-4, k
+        moved += rel(w0, w) > 1e-3
+    assert moved >= 20                                                   # the jitter is really in the gradient
+
+
+def test_report_of_attempts_under_training(capsys, monkeypatch):
+    """check_cholesky = "sync": the training forward prints the reference's WARNING instead of raising."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build("mini_mnist")
+    head = find_head(dens)
+    orig = E.gram_cholesky
+
+    def forced(T, d, max_attempts=6, eps0=1e-6):
+        r = orig(T, d, 1)
+        r.fail[0] = 1
+        E.cholesky_retries(r, d, max_attempts, eps0)
+        return r
+
+    monkeypatch.setattr(E, "gram_cholesky", forced)
+    dens.train()
+    with torch.enable_grad():
+        out = inner(dens, True).elbo(g["x"].float().cuda(), add_offdiagonal_metric_reg=True)
+        (-out["elbo"].mean()).backward()
+    assert "2 attempts needed" in capsys.readouterr().out
+    assert set(out["prior-dict"]) == {"elbo", "low-dim-x"}              # the training path returns the no-grad path's keys
+    with pytest.raises(RuntimeError, match="second time"):
+        (-out["elbo"].mean()).backward()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# FlatOptimizer: updated weights must reach the kernels
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def test_flat_optimizer_steps_reach_the_conv_kernels():
+    """The fused step writes the flat buffer with a raw kernel: no tensor version moves.  After two steps the model must
+    evaluate like a FRESH model built from its state_dict() (the packed weight copies were stale cache hits in round 1), and
+    three FlatOptimizer steps must equal three torch.optim.Adam steps on a twin."""
+    import cmf_amd
+    from cmf_amd.optim import FlatOptimizer
+    from cmf_amd.training import train_batch
+    g, meta, cfg, dens = build("mini_mnist")
+    _, _, _, twin = build("mini_mnist")
+    d1, d2 = inner(dens, True), inner(twin, True)
+    tcfg = dict(cfg, g_ij_loss=True, g_kk_loss=False)
+    train_metrics, _, _ = cmf_amd.get_non_square_train_metrics(tcfg)
+    x0 = g["x"].float().cuda()
+    kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=True)
+    with torch.no_grad():
+        d1.eval()
+        before = d1.elbo(x0.clone(), **kw)["elbo"].clone()
+    flat = FlatOptimizer(d1.parameters(), opt="adam", lr=3e-3)
+    ref = torch.optim.Adam(d2.parameters(), lr=3e-3)
+    l1, l2 = [], []
+    for it in range(3):
+        l1.append(float(train_batch(d1, x0.clone(), 10_000, train_metrics, [flat])["metrics"]["loss"].detach()))
+        l2.append(float(train_batch(d2, x0.clone(), 10_000, train_metrics, [ref])["metrics"]["loss"].detach()))
+    assert np.allclose(l1, l2, rtol=2e-5), (l1, l2)                      # identical trajectories, step by step
+    assert l1[1] != l1[0]
+    for (k, p), (_, q) in zip(d1.named_parameters(), d2.named_parameters()):
+        assert rel(p, q) < 2e-4, k
+    d1.eval()
+    with torch.no_grad():
+        after = d1.elbo(x0.clone(), **kw)["elbo"]
+        fresh = cmf_amd.get_density(cmf_amd.get_schema(cfg), g["x"])
+        fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in dens.state_dict().items()})
+        fresh = fresh.cuda().eval()
+        want = inner(fresh, True).elbo(x0.clone(), **kw)["elbo"]
+    assert rel(after, want) < 1e-6                                       # the kernels saw the updated conv weights
+    assert rel(after, before) > 1e-4                                     # and the parameters did move
+
+
+def test_weighted_gradient_allreduce_single_rank_is_identity():
+    from cmf_amd.optim import FlatOptimizer
+    g, meta, cfg, dens = build("c1_sphere")
+    opt = FlatOptimizer(dens.parameters(), opt="sgd", lr=1e-2)
+    opt.grad.normal_()
+    before = opt.grad.clone()
+    opt.allreduce_flat(n_local=7)
+    assert torch.equal(opt.grad, before)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# nested prior-dict (opt-in)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("name", ["c1_sphere", "mini_mnist", "mini_cifar", "c2b_hepmass"])
+def test_nested_prior_dict_matches_the_reference_chain(name):
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    head.nested_prior_dict = True
+    with torch.no_grad():
+        out = head.elbo(g["head_input"].cuda(), add_offdiagonal_metric_reg=True)
+    assert rel(out["elbo"] + g["prehead_logjac"].cuda(), g["elbo_0"]) < 1e-4
+    node, level = out["prior-dict"], 0
+    while isinstance(node, dict):
+        assert sorted(node.keys()) == meta["nested_keys"][level], (level, sorted(node.keys()))
+        assert rel(node["elbo"], g["nested_elbo"][level]) < 2e-5, level
+        if "low-dim-x" in node:
+            assert rel(node["low-dim-x"], g["z_low"]) < 1e-5
+        node = node.get("prior-dict")
+        level += 1
+    assert level == g["nested_elbo"].shape[0]
+    head.nested_prior_dict = False
+    with torch.no_grad():
+        flat = head.elbo(g["head_input"].cuda(), add_offdiagonal_metric_reg=True)
+    assert set(flat["prior-dict"]) == {"elbo", "low-dim-x"} and torch.equal(flat["elbo"], out["elbo"])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a14: metric term on the Hutchinson product (S == d)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("name,diag", [("mini_mnist", False), ("mini_cifar", True), ("c2b_hepmass", False)])
+def test_hutchinson_metric_term_and_its_gradients(name, diag):
+    """num_hutchinson_samples == latent_dimension: the reference's train-mode objective adds the L1 of the off-diagonal (or
+    diagonal) entries of W = (J^T J) eps (non_square.py:87-100 on the third return value of :253-258).  Forward values
+    against the float64 oracle; parameter gradients against autograd through it with u = solve(J^T J, eps).detach()."""
+    from oracle import cmf_oracle as O
+    g, meta, cfg, dens = build(name)
+    _, schema, x_shape, ops, sd = golden_model(meta, dtype=torch.float64)
+    head = find_head(dens)
+    named = dict(dens.named_parameters())
+    B, d = min(3, g["z_low"].shape[0]), head.program.d
+    S = d
+    head.log_jacobian_method, head.num_hutchinson_samples, head.max_cg_iterations, head.cg_tolerance = "hutch_with_cg", S, 4 * d, 1e-7
+    gen = torch.Generator().manual_seed(78)
+    z_low, eps = g["z_low"][:B].float(), torch.randn(B, d, S, generator=gen)
+    a, c = torch.randn(B, generator=gen), torch.rand(B, generator=gen) + 0.5
+    keys = [k for k, v in sd.items() if v.is_floating_point() and k in named]
+    sd64 = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    pre, hd, flow_ops, base, prior_ops = O.split_ops(ops)
+    jtj, xh, J = O.jtj_batched(sd64, flow_ops, base, z_low.double())
+    w = torch.bmm(jtj, eps.double())
+    u = torch.linalg.solve(jtj, eps.double()).detach()
+    value = (u * w).sum(1).mean(1)
+    l1 = O.metric_l1(w, diag).flatten()
+    want = torch.autograd.grad((a.double() * value + c.double() * l1).sum(), [sd64[k] for k in keys], allow_unused=True)
+    st = head.head_terms_forward(z_low.cuda(), tangents=True, hutch_eps=eps.cuda())
+    assert rel(st["hutch"]["l1_diag" if diag else "l1_off"], l1) < 1e-4
+    out = head.head_terms_backward(z_low.cuda(), None, g_logdet=a.cuda(), state=st,
+                                   **{"g_l1diag" if diag else "g_l1off": c.cuda()})
+    checked = 0
+    for k, wv in zip(keys, want):
+        if wv is not None and float(wv.abs().max()) > 0:
+            assert rel(out["grads"][named[k]], wv.reshape(named[k].shape)) < 2e-3, k
+            checked += 1
+    assert checked >= (40 if len(x_shape) == 3 else 10)
+    # through the public API, train mode: elbo = (low - value / 2) - lam rec - wm l1(W)
+    dens.train()
+    x = g["x"][:B].float().cuda()
+    kw = {"add_diagonal_metric_reg" if diag else "add_offdiagonal_metric_reg": True}
+    with torch.no_grad():
+        torch.manual_seed(5)
+        got = inner(dens, "noise" in g).elbo(x.clone(), metric_wt=0.7, **kw)["elbo"]
+        h = head.last_hutchinson
+        torch.manual_seed(5)
+        base_elbo = inner(dens, "noise" in g).elbo(x.clone(), metric_wt=0.7)["elbo"]
+    l1_api = O.metric_l1(h["w"].cpu().double(), diag)
+    assert rel(got, base_elbo.cpu().double() - 0.7 * l1_api) < 1e-5
+    head.num_hutchinson_samples = max(1, d - 1)
+    with pytest.raises(ValueError, match="num_hutchinson_samples"):
+        inner(dens, "noise" in g).elbo(x.clone(), **kw)
+
+
+def test_hutchinson_cg_probe_chunks():
+    """S > 16 probes run in chunks of 16 (one workgroup per sample and chunk): u, w and the value equal the exact solve."""
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(3)
+    for B, d, S in ((5, 64, 64), (3, 128, 128), (4, 21, 40)):
+        A = torch.randn(B, d + 8, d, generator=gen, dtype=torch.float64)
+        G = torch.bmm(A.transpose(1, 2), A) / d + 0.5 * torch.eye(d, dtype=torch.float64)
+        eps = torch.randn(B, d, S, generator=gen, dtype=torch.float64)
+        val, u, w, iters = E.hutch_cg(G.float().cuda(), eps.float().cuda(), 4 * d, 1e-7)
+        assert rel(w, torch.bmm(G, eps)) < 1e-5
+        assert rel(u, torch.linalg.solve(G, eps)) < 1e-3
+        assert rel(val, (eps ** 2).sum(1).mean(1)) < 1e-3
+        assert int(iters.min()) >= 1
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bench.py launches its own ranks
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def _bench(*argv, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=env,
+                       timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_launches_two_ranks_from_a_bare_shell():
+    """``python bench.py --gpus 2`` with no launcher around it: the parent spawns the ranks (gloo + one shared GPU here: a
+    rehearsal of the RCCL launch on a one-GPU box), relays ONE JSON line, world size as the process group saw it."""
+    line = _bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--batch", "32", "--steps", "1", "--warmup", "1",
+                  "--cpu-batch", "0")
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
+    assert line["value"] > 0 and "REHEARSAL" in line["data"]
+    assert "cpu_baseline" not in line and "f32_exact" not in line
+
+
+@pytest.mark.parametrize("config", ["c1", "c2b"])
+def test_bench_other_configs_print_the_contract(config):
+    line = _bench("--config", config, "--steps", "3", "--cpu-batch", "64")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# two devices in one process (the threading contract of SURVEY 8b)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
+def test_two_devices_one_process():
+    """Kernel attributes (dynamic LDS limit) are per device: the second device of a process must get its own."""
+    import threading
+    g, meta, cfg, dens0 = build("mini_mnist")
+    x = g["x"].float()
+    outs = {}
+
+    def run(dev):
+        torch.cuda.set_device(dev)
+        import cmf_amd
+        from cmf_amd.recipe import fill_state_dict
+        dens = cmf_amd.get_density(cmf_amd.get_schema(cfg), g["x"])
+        dens.load_state_dict(fill_state_dict(dens.state_dict(), seed=meta["recipe_seed"]))
+        dens = dens.to(f"cuda:{dev}").eval()
+        with torch.no_grad():
+            outs[dev] = inner(dens, True).elbo(x.to(f"cuda:{dev}"), add_offdiagonal_metric_reg=True)["elbo"].cpu()
+
+    threads = [threading.Thread(target=run, args=(d,)) for d in (1, 0)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert rel(outs[0], outs[1]) < 1e-6
