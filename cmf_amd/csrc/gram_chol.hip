@@ -53,7 +53,8 @@ __device__ int block_cholesky(float* G, int ldg, int d, float* logdet) {
 // (ti + 16a, tj + 16c).  Per step only column k goes through LDS (double-buffered: one barrier per step): its owners
 // publish it, everyone reads the pivot, NT row factors and NT column values and updates its registers.  For j <= i the
 // arithmetic is that of block_cholesky (G_ij -= (G_ik / p_k) G_jk); the mirror half is computed but never read.
-typedef unsigned int u32x4 __attribute__((vector_size(16)));   // the type raw_buffer_load_b128 returns
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // the type raw_buffer_load_b128 returns
 
 template <int NT>
 __device__ int block_cholesky_reg(const float* G, int ldg, int d, float* colbuf, float* logdet) {
@@ -367,6 +368,232 @@ __global__ __launch_bounds__(256) void gram_chol_direct_kernel(const float* __re
   report(b, inf, ld, logdet, info, fail + 0);
 }
 
+
+#ifdef CMF_DBG_GSTAMP
+// diagnostic build only (tools/build_dbg.sh GSTAMP): phase time stamps of every workgroup of the d <= 64 kernel
+__device__ unsigned long long cmf_dbg_gram_stamps[4096][4];
+extern "C" int cmf_debug_read_gram_stamps(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cmf_dbg_gram_stamps), sizeof(cmf_dbg_gram_stamps));
+}
+#define GSTAMP(k)                                                                    \
+  do {                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {                                      \
+      unsigned long long t_;                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+      cmf_dbg_gram_stamps[blockIdx.x][k] = t_;                                        \
+    }                                                                                 \
+  } while (0)
+#else
+#define GSTAMP(k) do {} while (0)
+#endif
+
+// d <= 64 (NC = 64): Gram, cross-wave reduction, J^T J / L1 output and the pivot-only elimination.
+// Phase stamps of the round-1 kernel (tools/bench_gram.py with the GSTAMP build; B = 512, D = 784, d = 64, s_memtime ~ 2.1 GHz):
+// Gram 56 k cycles for the two co-resident workgroups of a CU = 90 % of the MFMA issue rate, but reduction + output 13 k and
+// the elimination 59 k cycles = 920 per step: its ~100 VALU instructions per step (four IEEE divisions, logf, address
+// arithmetic of nine LDS reads) were the critical path, not the barrier.  This kernel keeps the Gram loop and rebuilds the rest:
+//   Gram      rows dealt to the four waves in 4-row groups (K split), every wave accumulates all 16 tiles (64 accumulator
+//             registers); loads run PF groups ahead in a register ring through a bounds-checked buffer descriptor.  Lane
+//             (kq, cl) feeds component t of its float4 as A and B operand element of column tile t, so accumulator tile
+//             (i, j), register r holds G[16 kq + 4 r + i][4 cl + j].
+//   reduce    every wave parks its partial Gram in its own LDS plane in ROW-MAJOR order (row stride 68 floats: a lane's four
+//             tiles j = 0..3 of one (i, r) are one ds_write_b128, the 16 lanes of a kq group write one contiguous row).
+//             Thread (tr, tc) = (tid / 16, tid % 16) then sums the 4 x 4 block rows 4 tr.., columns 4 tc.. over the four
+//             planes (16 conflict-free ds_read_b128) and owns it in registers: J^T J leaves as four 16-byte stores per
+//             thread, the L1 terms are register sums.
+//   Cholesky  symmetric pivot-only elimination on those registers, one column per barrier, two ds_read_b128 per thread and
+//             step (see the loop).  Pivots are kept in LDS and their logs are summed after the loop, off the critical path.
+// workgroup barrier for LDS traffic only (``__syncthreads`` also drains vmcnt: outstanding global stores)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int PF>
+__global__ __launch_bounds__(256) void gram_chol64_kernel(const float* __restrict__ t, long long t_b, long long t_r,
+                                                           int n_rows, int d, float* __restrict__ jtj,
+                                                           float* __restrict__ logdet, float* __restrict__ l1_off,
+                                                           float* __restrict__ l1_diag, int* __restrict__ info,
+                                                           int* __restrict__ fail) {
+  constexpr int NT = 4, NC = 64, LDP = 68, PLANE = NC * LDP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // 4 planes x 64 rows x 68 floats = 69.6 KB
+  __shared__ __attribute__((aligned(16))) float colB[2][NC];        // column k, double-buffered
+  __shared__ float pivs[NC];
+  __shared__ float red[16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, cl = lane & 15;
+  const int b = blockIdx.x;
+  GSTAMP(0);
+
+  f32x4 acc[NT][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ngroups_all = (n_rows + 3) >> 2;
+  const int ngroups = (ngroups_all + 3 - wave) / 4;                 // this wave's 4-row groups: wave, wave + 4, ...
+  const char* panel = reinterpret_cast<const char*>(t + (long long)b * t_b);
+  const int panel_bytes = (int)((long long)n_rows * t_r * 4);
+  const int row_bytes = (int)t_r * 4;
+  const int group_bytes = 16 * row_bytes;
+  const int voff = (wave * 4 + kq) * row_bytes + cl * NT * 4;
+  int goff = 0;
+  u32x4 ring[PF];
+  auto load = [&](int slot) {
+    const int left = panel_bytes - goff;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(panel + goff), 0, left > 0 ? left : 0, 0x00020000);
+    ring[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    goff += group_bytes;
+  };
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    load(s);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  auto consume = [&](int s) {
+    float comp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const unsigned u = ring[s][j];
+      comp[j] = __builtin_bit_cast(float, u);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp[i], comp[j], acc[i][j], 0, 0, 0);
+  };
+  int g0 = 0;
+  for (; g0 + PF <= ngroups; g0 += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      consume(s);
+      load(s);                                      // past the panel's end the descriptor returns zeros without traffic
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // the remaining ngroups % PF groups, exactly: an all-zero group still costs its 16 MFMAs (49 groups per wave at D = 784:
+  // rounding up to a multiple of PF = 8 was 14 % more matrix work)
+  const int rem = ngroups - g0;
+#pragma unroll
+  for (int s = 0; s < PF - 1; ++s)
+    if (s < rem) consume(s);                        // uniform
+  GSTAMP(1);
+
+  // park the partial Gram of this wave row-major in its plane: G[16 kq + 4 r + i][4 cl + (0..3)]
+  float* plane = smem + wave * PLANE;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<f32x4*>(plane + (16 * kq + 4 * r + i) * LDP + 4 * cl) =
+          f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+  __syncthreads();
+  const int tr = tid >> 4, tc = tid & 15;           // this thread: rows 4 tr .. 4 tr + 3 x columns 4 tc .. 4 tc + 3
+  float g[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* src = smem + (4 * tr + i) * LDP + 4 * tc;
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(src), p1 = *reinterpret_cast<const f32x4*>(src + PLANE);
+    const f32x4 p2 = *reinterpret_cast<const f32x4*>(src + 2 * PLANE), p3 = *reinterpret_cast<const f32x4*>(src + 3 * PLANE);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[i][e] = (p0[e] + p1[e]) + (p2[e] + p3[e]);
+  }
+
+  // J^T J out and the L1 terms, from registers
+  float so = 0.f, sd = 0.f;
+  float* gout = jtj + (long long)b * d * d;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * tr + i;
+    if (row < d) {
+      if (d == NC) {
+        *reinterpret_cast<f32x4*>(gout + row * NC + 4 * tc) = f32x4{g[i][0], g[i][1], g[i][2], g[i][3]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (4 * tc + c < d) gout[row * d + 4 * tc + c] = g[i][c];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float a = fabsf(g[i][c]);             // columns >= d are exact zeros (zero J columns)
+        if (row == 4 * tc + c) sd += a; else so += a;
+      }
+    }
+  }
+  GSTAMP(2);
+
+  // Pivot-only symmetric elimination in registers, G_ij -= (G_ik / p_k) G_jk.  What bounds a step is LDS traffic and VALU
+  // issue, not the barrier (GSTAMP builds: a row x 16-column ownership read 5 b128 per thread and column = 20 KB per
+  // workgroup, 600 cycles per column with two workgroups per CU -- and pairing two columns per barrier changed nothing):
+  // with 4 x 4 blocks a thread needs its four row values and four column values of column k (two ds_read_b128) plus the
+  // pivot.  The row factors are a_i * (1 / p_k) with ONE IEEE division per step (exact for the power-of-two matrices of the
+  // retry fixture; on an exactly singular general matrix the sign of the rounding-level pivot is as arbitrary as LAPACK's).
+  // The body is branch-free apart from the uniform k < d guard: a `break` on a bad pivot kept hipcc from unrolling the column
+  // slots (the published register then went through s_set_gpr_idx and the block was copied twice per step); a bad pivot
+  // is remembered and the remaining steps run on garbage.
+  int inf = 0;
+#pragma unroll 1
+  for (int m = 0; m < 16; ++m) {
+    if (4 * m >= d) break;                          // uniform
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = 4 * m + c;
+      if (k < d) {                                  // uniform
+        float* cb = colB[k & 1];
+        if (tc == m) {
+          *reinterpret_cast<f32x4*>(cb + 4 * tr) = f32x4{g[0][c], g[1][c], g[2][c], g[3][c]};
+          if (tr == m) pivs[k] = g[c][c];
+        }
+        lds_barrier();                              // LDS visibility only: no vmcnt(0) (the J^T J stores are in flight)
+        const float piv = cb[k];
+        const f32x4 av = *reinterpret_cast<const f32x4*>(cb + 4 * tr);
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(cb + 4 * tc);
+        if ((!(piv > 0.f) || !(piv < 3.0e38f)) && !inf) inf = k + 1;
+        float rp = __builtin_amdgcn_rcpf(piv);      // 1 ulp, then one Newton step: a correctly rounded reciprocal for all
+        rp = __builtin_fmaf(__builtin_fmaf(-piv, rp, 1.0f), rp, rp);   // but a few operands; exact for powers of two
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float l = av[i] * rp;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[i][e] -= l * rv[e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float ld = (!inf && tid < d) ? logf(pivs[tid]) : 0.f;
+  ld = wave_sum(ld);
+  so = wave_sum(so);
+  sd = wave_sum(sd);
+  if (lane == 0) {
+    red[wave] = ld;
+    red[4 + wave] = so;
+    red[8 + wave] = sd;
+  }
+  __syncthreads();
+  ld = (red[0] + red[1]) + (red[2] + red[3]);
+  GSTAMP(3);
+  if (tid == 0) {
+    l1_off[b] = (red[4] + red[5]) + (red[6] + red[7]);
+    l1_diag[b] = (red[8] + red[9]) + (red[10] + red[11]);
+  }
+  report(b, inf, ld, logdet, info, fail + 0);
+}
+
+template <int PF>
+int launch_gram64(const float* t, long long t_b, long long t_r, int n_rows, int d, int B, float* jtj, float* logdet,
+                  float* l1_off, float* l1_diag, int* info, int* fail, hipStream_t s) {
+  constexpr int lds = 4 * 64 * 68 * 4;
+  auto k = gram_chol64_kernel<PF>;
+  if (hipError_t e = cmf_set_dynamic_lds((const void*)k, lds); e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k, dim3(B), dim3(256), lds, s, t, t_b, t_r, n_rows, d, jtj, logdet, l1_off, l1_diag, info, fail);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int NT>
 int launch_gram_direct(const float* t, long long t_b, long long t_r, int n_rows, int d, int B, float* jtj, float* logdet,
                        float* l1_off, float* l1_diag, int* info, int* fail, hipStream_t s) {
@@ -415,7 +642,13 @@ extern "C" int cmf_gram_cholesky(const float* t, long long t_b, long long t_r, i
   // hipGraphLaunch on (ROCm 7.2, observed as pointer-like values in the flags), which silently armed every retry.
   hipLaunchKernelGGL(zero_flags_kernel, dim3(1), dim3(64), 0, s, fail);
   CMF_LAUNCH_CHECK();
+#ifdef CMF_DBG_GRAMOLD
   if (nc == 64) return launch_gram_direct<4>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
+#endif
+#ifndef CMF_DBG_GRAMPF
+#define CMF_DBG_GRAMPF 8                            // measured: 8 groups ahead beat 12 / 16 / 24 by 3 - 12 us at B = 512
+#endif
+  if (nc == 64) return launch_gram64<CMF_DBG_GRAMPF>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
   if (nc == 128) return launch_gram_direct<8>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
 #define CMF_GRAM_CASE(N) \
   case N: return launch_gram<N>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
