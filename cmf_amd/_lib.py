@@ -80,6 +80,9 @@ SIGNATURES = {
     "cmf_recon_sqerr": (_i, [_fp, _fp, _i, _i, _fp, _fp]),
     "cmf_elbo_combine": (_i, [_fp, _fp, _fp, _fp, _fp, _f, _f, _f, _i, _fp, _fp]),
     "cmf_hutch_cg": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _fp, _fp]),
+    "cmf_rq_spline": (_i, [_fp, _ll, _fp, _i, _i, _i, _f, _i, _i, _fp, _ll, _fp, _fp]),
+    "cmf_lu_weights": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp]),
+    "cmf_made_mask_weight": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp]),
     "cmf_hutch_metric": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp]),
     "cmf_hutch_cotangent": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
 }

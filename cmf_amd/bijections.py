@@ -19,6 +19,7 @@ import torch.nn as nn
 from . import engine as E
 
 __all__ = [
+    "RandomChannelwisePermutationBijection", "LULinearBijection", "AutoregressiveRationalQuadraticSplineBijection",
     "Bijection", "AffineCouplingBijection", "Checkerboard2dAffineCouplingBijection",
     "SplitChannelwiseAffineCouplingBijection", "AlternatingChannelwiseAffineCouplingBijection", "ViewBijection",
     "Squeeze2dBijection", "AffineBijection", "LogitBijection", "ScalarMultiplicationBijection",
@@ -385,6 +386,180 @@ class Squeeze2dBijection(_ReshapingBijection):
     def _reshape_z(self, z):
         f, (C, H, W) = self.factor, self.x_shape
         return z.reshape(-1, C, f, f, H // f, W // f).permute(0, 1, 4, 2, 5, 3).reshape(-1, *self.x_shape)
+
+
+# --------------------------------------------------------------------------------------------------
+# NSF prior layers (schemas.py:87-103,586-626): PARITY UNPINNED -- jrmcornish/nsf @ 8e3fe75 is not vendored
+# under the reference tree; built from the published algorithm (csrc/nsf.hip), tested against oracle/cmf_oracle.py's
+# restatement.  Module / parameter names follow the nsf code base so that the state-dict keys are the reference's:
+#   bijection.{permutation, inverse_permutation}
+#   bijection.linear.{bias, lower_entries, upper_entries, unconstrained_upper_diag}
+#   bijection.flow.autoregressive_net.{initial_layer, blocks.i.linear_layers.j, final_layer}.{weight, bias, mask, degrees}
+# These layers sit BELOW the tail: they act on (B, d) latents in the encode / sampling directions only, no tangents.
+# --------------------------------------------------------------------------------------------------
+
+
+class _PriorFlowLayer(Bijection):
+    """A low-dimensional prior layer evaluated out of place: ``prior_encode(u, lj) -> z`` (lj (B,) accumulates the
+    log-jacobian) and ``prior_decode(z) -> u`` as the reference's ``z_to_x`` computes it."""
+
+    def prior_encode(self, u, lj=None):
+        raise NotImplementedError
+
+    def prior_decode(self, z):
+        raise NotImplementedError
+
+    def _x_to_z(self, x):
+        E.require_gpu(x)
+        lj = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+        return {"z": self.prior_encode(x.detach().contiguous(), lj), "log-jac": lj.view(-1, 1)}
+
+    def _z_to_x(self, z):
+        # the wrappers return a log-jac too; the hot path never reads it in this direction (sampling)
+        E.require_gpu(z)
+        x = self.prior_decode(z.detach().contiguous())
+        return {"x": x, "log-jac": -self._x_to_z(x)["log-jac"]}
+
+
+class RandomChannelwisePermutationBijection(_PriorFlowLayer):
+    """z = x[:, permutation] (reshaping.py:32-43); the permutation is drawn at construction and saved in checkpoints."""
+
+    def __init__(self, x_shape):
+        assert len(x_shape) == 1
+        super().__init__(x_shape, x_shape)
+        self.register_buffer("permutation", torch.randperm(x_shape[0]))
+        self.register_buffer("inverse_permutation", torch.argsort(self.permutation))
+
+    def prior_encode(self, u, lj=None):
+        return E.gather_primal(u, self.permutation.to(torch.int32), u.shape[1])
+
+    def prior_decode(self, z):
+        return E.gather_primal(z, self.inverse_permutation.to(torch.int32), z.shape[1])
+
+
+class _LULinearParameters(nn.Module):
+    """Parameter container with the names (and registration order) of nsf's ``LULinear(features, identity_init=True)``."""
+
+    def __init__(self, features, eps=1e-3):
+        super().__init__()
+        self.features, self.eps = features, eps
+        n_tri = (features - 1) * features // 2
+        self.bias = nn.Parameter(torch.zeros(features))
+        self.lower_entries = nn.Parameter(torch.zeros(n_tri))
+        self.upper_entries = nn.Parameter(torch.zeros(n_tri))
+        self.unconstrained_upper_diag = nn.Parameter(torch.full((features,), float(np.log(np.exp(1 - eps) - 1))))
+
+
+class LULinearBijection(_PriorFlowLayer):
+    """z = L (U x) + b, log-jac = sum log diag(U) (bijections/linear.py:12-28 -> nsf LULinear)."""
+
+    def __init__(self, num_input_channels):
+        super().__init__((num_input_channels,), (num_input_channels,))
+        self.linear = _LULinearParameters(num_input_channels)
+
+    def _affine_map(self, u, lj):
+        p = self.linear
+        W, ld = E.lu_weights(p.lower_entries, p.upper_entries, p.unconstrained_upper_diag, p.eps)
+        if lj is not None:
+            lj += ld                                   # the same constant for every sample
+        return E.linear_primal(u, W, p.bias.detach())
+
+    def prior_encode(self, u, lj=None):
+        return self._affine_map(u, lj)
+
+    def prior_decode(self, z):
+        # bijections/linear.py:30-34: ``_z_to_x`` calls ``self.linear(z)`` -- the FORWARD map, not the inverse.  Kept as is:
+        # samples drawn through an nsf prior see L U z + b here exactly as in the reference (the density path is unaffected).
+        return self._affine_map(z, None)
+
+
+class _MaskedLinear(nn.Linear):
+    """nsf's MaskedLinear: an nn.Linear with ``mask`` / ``degrees`` buffers (random_mask = False)."""
+
+    def __init__(self, in_degrees, out_features, autoregressive_features, is_output):
+        super().__init__(len(in_degrees), out_features, bias=True)
+        if is_output:
+            out_degrees = torch.arange(1, autoregressive_features + 1).repeat_interleave(out_features // autoregressive_features)
+            mask = (out_degrees[:, None] > in_degrees[None, :]).float()
+        else:
+            max_, min_ = max(1, autoregressive_features - 1), min(1, autoregressive_features - 1)
+            out_degrees = torch.arange(out_features) % max_ + min_
+            mask = (out_degrees[:, None] >= in_degrees[None, :]).float()
+        self.register_buffer("mask", mask)
+        self.register_buffer("degrees", out_degrees)
+        self.kind = 2 if is_output else None           # 0 / 1 set by the owner (input or hidden source)
+
+    forward = None
+
+
+class _MaskedResidualBlock(nn.Module):
+    def __init__(self, in_degrees, autoregressive_features):
+        super().__init__()
+        features = len(in_degrees)
+        l0 = _MaskedLinear(in_degrees, features, autoregressive_features, False)
+        l1 = _MaskedLinear(l0.degrees, features, autoregressive_features, False)
+        l0.kind = l1.kind = 1
+        self.linear_layers = nn.ModuleList([l0, l1])
+        self.degrees = l1.degrees
+        nn.init.uniform_(l1.weight, -1e-3, 1e-3)       # zero_initialization=True
+        nn.init.uniform_(l1.bias, -1e-3, 1e-3)
+
+
+class _MADE(nn.Module):
+    def __init__(self, features, hidden_features, num_blocks, output_multiplier):
+        super().__init__()
+        self.features, self.hidden_features, self.multiplier = features, hidden_features, output_multiplier
+        self.initial_layer = _MaskedLinear(torch.arange(1, features + 1), hidden_features, features, False)
+        self.initial_layer.kind = 0
+        deg = self.initial_layer.degrees
+        blocks = []
+        for _ in range(num_blocks):
+            blocks.append(_MaskedResidualBlock(deg, features))
+            deg = blocks[-1].degrees
+        self.blocks = nn.ModuleList(blocks)
+        self.final_layer = _MaskedLinear(deg, features * output_multiplier, features, True)
+
+    def evaluate(self, x):
+        """(B, D) -> (B, D * multiplier) spline parameters: masked linear layers through cmf_conv_primal (taps = 1), relu on
+        load, residual add in the epilogue."""
+        F_, K = self.features, self.multiplier
+        w = lambda lin: E.made_masked_weight(lin.weight, lin.kind, F_, K)
+        h = E.linear_primal(x, w(self.initial_layer), self.initial_layer.bias.detach())
+        for blk in self.blocks:
+            l0, l1 = blk.linear_layers
+            t = E.linear_primal(h, w(l0), l0.bias.detach(), relu_in=True)
+            h = E.linear_primal(t, w(l1), l1.bias.detach(), relu_in=True, res=h)
+        return E.linear_primal(h, w(self.final_layer), self.final_layer.bias.detach())
+
+
+class _AutoregressiveSplineFlow(nn.Module):
+    def __init__(self, features, hidden_features, num_blocks, num_bins, tail_bound):
+        super().__init__()
+        self.num_bins, self.tail_bound = num_bins, tail_bound
+        self.autoregressive_net = _MADE(features, hidden_features, num_blocks, 3 * num_bins - 1)
+
+
+class AutoregressiveRationalQuadraticSplineBijection(_PriorFlowLayer):
+    """Masked autoregressive rational-quadratic spline (bijections/nsf.py:86-113 -> nsf
+    MaskedPiecewiseRationalQuadraticAutoregressiveTransform with tails = 'linear', residual MADE, relu, no dropout)."""
+
+    def __init__(self, num_input_channels, num_hidden_layers, num_hidden_channels, num_bins, tail_bound):
+        super().__init__((num_input_channels,), (num_input_channels,))
+        self.flow = _AutoregressiveSplineFlow(num_input_channels, num_hidden_channels, num_hidden_layers, num_bins, tail_bound)
+
+    def prior_encode(self, u, lj=None):
+        f = self.flow
+        params = f.autoregressive_net.evaluate(u)
+        return E.rq_spline(u, params, f.num_bins, f.autoregressive_net.hidden_features, f.tail_bound, inverse=False, lj=lj)
+
+    def prior_decode(self, z):
+        """AutoregressiveTransform.inverse: D passes of (MADE, elementwise inverse spline); pass i fixes feature i."""
+        f = self.flow
+        x = torch.zeros_like(z)
+        for _ in range(z.shape[1]):
+            params = f.autoregressive_net.evaluate(x)
+            x = E.rq_spline(z, params, f.num_bins, f.autoregressive_net.hidden_features, f.tail_bound, inverse=True)
+        return x
 
 
 # --------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as E
-from .bijections import AffineBijection, AffineCouplingBijection, _Elementwise, _ReshapingBijection
+from .bijections import AffineBijection, AffineCouplingBijection, _Elementwise, _PriorFlowLayer, _ReshapingBijection
 
 __all__ = ["Density", "BijectionDensity", "SplitDensity", "DiagonalGaussianDensity", "WrapperDensity",
            "DequantizationDensity", "DataParallelDensity", "NonSquareHeadDensity", "ManifoldFlowHeadDensity",
@@ -303,8 +303,8 @@ class FlowProgram:
             if isinstance(m, AffineCouplingBijection) and m.geom.image != self.image:
                 raise NotImplementedError("mixed image / flat coupling stacks between head and base are not built")
         for m in self.prior:
-            if not isinstance(m, (AffineCouplingBijection, AffineBijection, _ReshapingBijection)):
-                raise NotImplementedError(f"prior layer {type(m).__name__} is outside the hot path (nsf: SURVEY f3)")
+            if not isinstance(m, (AffineCouplingBijection, AffineBijection, _ReshapingBijection, _PriorFlowLayer)):
+                raise NotImplementedError(f"prior layer {type(m).__name__} is outside the hot path")
 
     # -- per-sample tangent footprint, for sub-batching ------------------------------------------
     def tangent_bytes_per_sample(self, nc):
@@ -356,6 +356,8 @@ class FlowProgram:
         for m in self.prior:
             if isinstance(m, (AffineCouplingBijection, AffineBijection)):
                 m.encode_(u, lj)
+            elif isinstance(m, _PriorFlowLayer):             # nsf prior layers: out of place
+                u = m.prior_encode(u, lj)
         self.gaussian.logprob_accumulate(u, lj)
         return z_low, lj, u
 
@@ -393,6 +395,8 @@ class FlowProgram:
             lj = zeros()
             if isinstance(m, (AffineCouplingBijection, AffineBijection)):
                 m.encode_(u, lj)
+            elif isinstance(m, _PriorFlowLayer):
+                u = m.prior_encode(u, lj)
             levels.append(("bijection", lj, u.clone()))
         lp = zeros()
         self.gaussian.logprob_accumulate(u, lp)
@@ -531,6 +535,9 @@ class FlowProgram:
         lj = torch.zeros(B, dtype=torch.float32, device=x.device)
         pctx = []
         for m in self.prior:
+            if isinstance(m, _PriorFlowLayer):
+                raise NotImplementedError("training gradients through the nsf prior layers (rand-channel-perm / LULinear / "
+                                          "autoregressive spline) are not built: evaluation and sampling only")
             if isinstance(m, (AffineCouplingBijection, AffineBijection)):
                 pctx.append((m, m.encode_train_(u, lj)))
         if self.gaussian._nonstandard():
@@ -567,6 +574,8 @@ class FlowProgram:
         for m in reversed(self.prior):
             if isinstance(m, (AffineCouplingBijection, AffineBijection)):
                 m.decode_(z)
+            elif isinstance(m, _PriorFlowLayer):
+                z = m.prior_decode(z)
         return z
 
 

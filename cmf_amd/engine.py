@@ -509,6 +509,77 @@ def hutch_cotangent(u, eps, w, g_val=None, g_off=None, g_diag=None):
     return M
 
 
+# --------------------------------------------------------------------------------------------------
+# NSF prior layers: derived weights are cached per parameter version like the packs
+# --------------------------------------------------------------------------------------------------
+
+
+class _DerivedCache:
+    """Tensors computed from parameters by a kernel (masked MADE weights, L U products), rebuilt when a source parameter
+    changes (``_version`` / storage / ``PACKS.generation``, which FlatOptimizer bumps).  A rebuilt entry is a NEW tensor, so
+    the pack cache keyed on the tensor's identity follows."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, sources, build):
+        import weakref
+        ver = tuple((s._version, s.data_ptr(), s.device) for s in sources) + (PACKS.generation,)
+        hit = self._store.get(key)
+        if hit is not None and hit[0]() is sources[0] and hit[1] == ver:
+            return hit[2]
+        out = build()
+        if len(self._store) > 4096:
+            self._store = {k: v for k, v in self._store.items() if v[0]() is not None}
+        self._store[key] = (weakref.ref(sources[0]), ver, out)
+        return out
+
+
+DERIVED = _DerivedCache()
+
+
+def made_masked_weight(weight, kind, features, multiplier=1):
+    """weight * MADE mask (kind 0 input->hidden, 1 hidden->hidden, 2 hidden->output) as a cached (out, in) tensor."""
+    def build():
+        w = weight.detach().contiguous()
+        out = torch.empty_like(w)
+        _lib.check(_lib.load().cmf_made_mask_weight(_p(w), _p(out), w.shape[0], w.shape[1], int(kind), int(features),
+                                                    int(multiplier), _stream()), "cmf_made_mask_weight")
+        return out
+    return DERIVED.get((id(weight), "made", kind, features, multiplier), [weight], build)
+
+
+def lu_weights(lower, upper, udiag, eps=1e-3):
+    """(W = L U (n, n), logabsdet (1,)) of an LULinear layer, cached per parameter version."""
+    def build():
+        n = udiag.shape[0]
+        W = torch.empty(n, n, dtype=torch.float32, device=udiag.device)
+        ld = torch.empty(1, dtype=torch.float32, device=udiag.device)
+        _lib.check(_lib.load().cmf_lu_weights(_p(lower.detach().contiguous()), _p(upper.detach().contiguous()),
+                                              _p(udiag.detach().contiguous()), n, float(eps), _p(W), _p(ld), _stream()),
+                   "cmf_lu_weights")
+        return W, ld
+    return DERIVED.get((id(udiag), "lu"), [udiag, lower, upper], build)
+
+
+def linear_primal(x, weight, bias, relu_in=False, res=None):
+    """y (B, out) = W [relu](x) + b [+ res] through ``cmf_conv_primal`` with taps = 1 (pixels = samples)."""
+    B, cin = x.shape
+    cout = weight.shape[0]
+    y = torch.empty(B, cout, dtype=torch.float32, device=x.device)
+    conv_primal(x, 0, 0, 1, cin, weight, 1, bias, y, 0, 1, cout, 1, cin, cout, 1, B, imode=F_RELU if relu_in else F_NONE, res=res)
+    return y
+
+
+def rq_spline(x, params, bins, hidden, tail_bound, inverse=False, lj=None):
+    """Elementwise rational-quadratic spline with linear tails on (B, D); params (B, D * (3 bins - 1)); lj (B,) accumulates."""
+    B, D = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().cmf_rq_spline(_p(x), D, _p(params), D, int(bins), int(hidden), float(tail_bound), int(inverse), B,
+                                         _p(out), D, _p(lj), _stream()), "cmf_rq_spline")
+    return out
+
+
 def prehead(x, noise, a, c, logit):
     B = x.shape[0]
     n = x[0].numel()

@@ -4,13 +4,14 @@ Same construction order, nesting and wrapping rules as the reference's
 ``cmf/models/factory.py:55-162`` (so that ``state_dict()`` keys coincide), restricted to the layer
 types a non-square model can contain: dequantization, scalar-mult / scalar-add / logit,
 non-square-head, acl (checkerboard / split-channel / alternating-channel with shared MLP or ResNet
-couplers), squeeze, flatten, split, non-square-base, affine.
+couplers), squeeze, flatten, split, non-square-base, affine, and the nsf prior's rand-channel-perm / linear / nsf-ar.
 """
 import numpy as np
 import torch
 
 from .bijections import (AffineBijection, AlternatingChannelwiseAffineCouplingBijection,
-                         Checkerboard2dAffineCouplingBijection, LogitBijection, ScalarAdditionBijection,
+                         AutoregressiveRationalQuadraticSplineBijection, Checkerboard2dAffineCouplingBijection,
+                         LogitBijection, LULinearBijection, RandomChannelwisePermutationBijection, ScalarAdditionBijection,
                          ScalarMultiplicationBijection, SplitChannelwiseAffineCouplingBijection, Squeeze2dBijection,
                          ViewBijection)
 from .densities import (BijectionDensity, DataParallelDensity, DequantizationDensity, DiagonalGaussianDensity,
@@ -82,6 +83,17 @@ def get_bijection(layer, x_shape):
         return ScalarAdditionBijection(x_shape=x_shape, value=layer["value"])
     if kind == "affine":
         return AffineBijection(x_shape=x_shape, per_channel=layer["per_channel"])
+    # the nsf prior of the low-dimensional flow (factory.py:287-314, schemas.py:87-103); parity unpinned (bijections.py)
+    if kind == "rand-channel-perm":
+        return RandomChannelwisePermutationBijection(x_shape=x_shape)
+    if kind == "linear":
+        assert len(x_shape) == 1
+        return LULinearBijection(num_input_channels=x_shape[0])
+    if kind == "nsf-ar":
+        assert len(x_shape) == 1 and layer["activation"] == "relu" and layer["dropout_probability"] == 0.
+        return AutoregressiveRationalQuadraticSplineBijection(
+            num_input_channels=x_shape[0], num_hidden_layers=layer["num_hidden_layers"],
+            num_hidden_channels=layer["num_hidden_channels"], num_bins=layer["num_bins"], tail_bound=layer["tail_bound"])
     raise ValueError(f"layer type {kind!r} is outside the non-square hot path")
 
 

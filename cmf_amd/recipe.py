@@ -36,8 +36,12 @@ def recipe_tensor(key, shape, dtype, seed, sibling_shapes=None):
     if leaf == "inverse_permutation":
         perm = _rng(key[: -len("inverse_permutation")] + "permutation", seed).permutation(shape[0])
         return torch.from_numpy(np.argsort(perm).astype(np.int64))
-    if leaf in ("mask", "mean", "stddev"):
+    if leaf in ("mask", "mean", "stddev", "degrees"):
         return None
+    if leaf in ("lower_entries", "upper_entries"):      # LULinear strict triangles (nsf prior): away from the identity init
+        return torch.from_numpy(rng.uniform(-0.2, 0.2, shape)).to(dtype)
+    if leaf == "unconstrained_upper_diag":              # softplus(.) + eps in (0.55, 1.5)
+        return torch.from_numpy(rng.uniform(-0.3, 1.2, shape)).to(dtype)
     if leaf == "_fixed_samples":
         return torch.from_numpy(rng.standard_normal(shape)).to(dtype)
     if leaf in ("shift", "log_scale"):          # AffineBijection (2-D prior)

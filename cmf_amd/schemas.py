@@ -141,8 +141,18 @@ def get_schema(config):
         tail.append({"type": "affine", "per_channel": False})
     elif config["prior"] == "realnvp":
         tail += _flat_realnvp(config["prior_num_density_layers"], config["prior_hidden_channels"])
+    elif config["prior"] == "nsf":
+        # schemas.py:87-103 (hard-coded 8 bins, tail bound 3, no dropout) -> get_nsf_schema :586-626 with use_linear and
+        # autoregressive; the 'normalise' layers are dropped (batch_norm False for every non-square config, :19-22)
+        tail.append({"type": "flatten"})
+        for _ in range(config["prior_num_density_layers"]):
+            tail += [{"type": "rand-channel-perm"}, {"type": "linear"},
+                     {"type": "nsf-ar", "num_hidden_channels": config["prior_hidden_channels"][0],
+                      "num_hidden_layers": len(config["prior_hidden_channels"]), "num_bins": 8, "tail_bound": 3.,
+                      "activation": "relu", "dropout_probability": 0.}]
+        tail += [{"type": "rand-channel-perm"}, {"type": "linear"}]
     else:
-        raise ValueError(f"prior {config['prior']!r} is not built (nsf: SURVEY.md f3, parity unpinned)")
+        raise ValueError(f"prior {config['prior']!r} is not a prior of the non-square models")
 
     pre = [{"type": "dequantization"}] if config["dequantize"] else []
     if config.get("logit_tf_lambda") is not None and config.get("logit_tf_scale") is not None:

@@ -276,6 +276,25 @@ int cmf_hutch_cotangent(const float* u, const float* eps, const float* w, int d,
                         const float* g_off, const float* g_diag, float* M, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * NSF prior of the low-dimensional flow (config/schemas.py:87-103 -> bijections/nsf.py:86-113,
+ * bijections/linear.py:12-34).  The arithmetic is jrmcornish/nsf @ 8e3fe75 (un-vendored: PARITY UNPINNED); implemented
+ * from Durkan et al., "Neural Spline Flows" (NeurIPS 2019) -- see csrc/nsf.hip.
+ * Elementwise monotone rational-quadratic spline with linear tails outside [-tail_bound, tail_bound]:
+ *   params [B][D][3 bins - 1] (bins widths, bins heights -- both divided by sqrt(hidden) as the autoregressive transform
+ *   does --, bins - 1 inner knot derivatives); out(b, f) = spline(x(b, f)) (inverse != 0: the inverse map);
+ *   lj[b] += sum_f log |d out / d x| (NULL to skip).  out may alias x.                                                */
+int cmf_rq_spline(const float* x, long long x_b, const float* params, int D, int bins, int hidden, float tail_bound,
+                  int inverse, int B, float* out, long long out_b, float* lj, void* stream);
+/* LULinear: W [n][n] = L U (L unit lower from `lower`, U upper from `upper` with diagonal softplus(unconstrained_diag) +
+ * eps; entry order of np.tril_indices(n, -1) / np.triu_indices(n, 1)); logdet[0] = sum log diag(U).                   */
+int cmf_lu_weights(const float* lower, const float* upper, const float* unconstrained_diag, int n, float eps, float* W,
+                   float* logdet, void* stream);
+/* out [n_out][n_in] = w * MADE mask (random_mask = False).  kind 0: input -> hidden, 1: hidden -> hidden, 2: hidden ->
+ * output with `multiplier` consecutive outputs per feature (strict inequality).  features = autoregressive width D.    */
+int cmf_made_mask_weight(const float* w, float* out, int n_out, int n_in, int kind, int features, int multiplier,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Non-convolution pieces of the coupler networks' primal backward.
  * ScaledTanh2dModule (networks.py:96-113), y = sw tanh(u) + sb, g = sw (1 - tanh(u)^2); y, g, dy, dg, du: (B, C, HW):
  *   du = dy g - 2 dg tanh(u) g;   dsw[c] += sum dy tanh(u) + dg (1 - tanh(u)^2);   dsb[c] += sum dy

@@ -10,7 +10,8 @@ Parity status: PINNED.  ``oracle/make_golden.py`` imports the reference itself (
 build container only) and writes ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
 checks every function below against those vectors.  The Hutchinson solve
 (``gpytorch.utils.linear_cg`` @ fc2053b, un-vendored) is the one exception: see
-``hutchinson_surrogate`` -- parity unpinned for the CG iterates, pinned for J^T J eps.
+``hutchinson_surrogate`` -- parity unpinned for the CG iterates, pinned for J^T J eps.  The NSF prior layers
+(``nsf_x_to_z``; jrmcornish/nsf @ 8e3fe75, un-vendored) are the other: parity unpinned, restated from the published algorithm.
 
 Two flavours of the Jacobian assembly are provided:
   * ``jtj_ref_equivalent``: one full decode per Jacobian column with the primal of every
@@ -73,6 +74,12 @@ def compile_schema(schema, x_shape):
                 assert not layer["per_channel"]
             elif t == "acl":
                 op.update(_acl_spec(layer, shape))
+            elif t in ("rand-channel-perm", "linear"):    # factory.py:287-292 (nsf prior only: schemas.py:87-103)
+                assert len(shape) == 1
+            elif t == "nsf-ar":                           # factory.py:304-314
+                assert len(shape) == 1 and layer["activation"] == "relu" and layer["dropout_probability"] == 0.
+                op.update(hidden=layer["num_hidden_channels"], blocks=layer["num_hidden_layers"], bins=layer["num_bins"],
+                          tail_bound=layer["tail_bound"])
             else:
                 raise ValueError(f"oracle: layer type {t!r} is outside the hot path")
             op["z_shape"] = shape
@@ -344,6 +351,150 @@ def gaussian_log_prob(w):
 LOGIT_EPS = 1e-7     # math.py:41-53
 
 
+
+# --------------------------------------------------------------------------------------
+# NSF prior: rand-channel-perm + LULinear + masked autoregressive rational-quadratic spline
+#
+# PARITY UNPINNED.  The reference builds these layers from jrmcornish/nsf @ 8e3fe75 (a fork of bayesiains/nsf,
+# .gitmodules:1-3), which is NOT under /root/reference (gitmodules/nsf is an empty directory), so no reference output can
+# be generated.  What follows restates the PUBLISHED algorithm -- Durkan, Bekasov, Murray, Papamakarios, "Neural Spline
+# Flows", NeurIPS 2019, and the public nsf code base's nde/transforms/{lu.py, autoregressive.py, made.py,
+# splines/rational_quadratic.py} -- anchored on the reference's call sites: bijections/nsf.py:86-113 (constructor
+# arguments: tails='linear', num_blocks, use_residual_blocks=True, random_mask=False, relu, no batch norm),
+# bijections/linear.py:12-34 (LULinear(identity_init=True)), bijections/reshaping.py:32-43, schemas.py:87-103,586-626
+# (NUM_BINS 8, TAIL_BOUND 3, layer order).  The tests check the restatement's own invariants (inverse o forward = id,
+# log-det = autograd Jacobian, autoregressive structure of the MADE masks), not reference vectors.
+# --------------------------------------------------------------------------------------
+
+NSF_KINDS = ("rand-channel-perm", "linear", "nsf-ar")
+MIN_BIN_WIDTH = MIN_BIN_HEIGHT = MIN_DERIVATIVE = 1e-3       # nsf defaults, not overridden at bijections/nsf.py:100-113
+LU_EPS = 1e-3                                                # LULinear(eps=1e-3)
+
+
+def lu_linear_matrices(sd, prefix):
+    """LULinear: W = L U with unit-lower L and U whose diagonal is softplus(unconstrained) + eps; logabsdet = sum log diag U."""
+    lo, up, ud = sd[prefix + "linear.lower_entries"], sd[prefix + "linear.upper_entries"], sd[prefix + "linear.unconstrained_upper_diag"]
+    n = ud.shape[0]
+    il, iu = np.tril_indices(n, k=-1), np.triu_indices(n, k=1)
+    L = torch.eye(n, dtype=ud.dtype)
+    L[il[0], il[1]] = lo
+    diag = F.softplus(ud) + LU_EPS
+    U = torch.diag(diag)
+    U[iu[0], iu[1]] = up
+    return L, U, torch.log(diag).sum()
+
+
+def made_degrees(features, hidden, blocks):
+    """Degrees of the MADE units (nde/made.py, random_mask=False): inputs 1..D, hidden units arange % max(1, D-1) + min(1, D-1)
+    in every hidden layer, outputs = input degrees tiled `multiplier` times (each feature's parameters contiguous)."""
+    d_in = torch.arange(1, features + 1)
+    max_, min_ = max(1, features - 1), min(1, features - 1)
+    d_hid = torch.arange(hidden) % max_ + min_
+    return d_in, d_hid
+
+
+def made_masks(features, hidden, multiplier):
+    d_in, d_hid = made_degrees(features, hidden, None)
+    m_init = (d_hid[:, None] >= d_in[None, :]).float()           # hidden <- input
+    m_hid = (d_hid[:, None] >= d_hid[None, :]).float()            # hidden <- hidden
+    d_out = d_in.repeat_interleave(multiplier)
+    m_out = (d_out[:, None] > d_hid[None, :]).float()             # output <- hidden: STRICT
+    return m_init, m_hid, m_out
+
+
+def made_forward(sd, op, x):
+    """MADE with masked residual blocks (pre-activation relu, x + W1 relu(W0 relu(x))), nde/made.py."""
+    p = op["prefix"] + "flow.autoregressive_net."
+    D, H, K = x.shape[1], op["hidden"], 3 * op["bins"] - 1
+    m_init, m_hid, m_out = made_masks(D, H, K)
+    m_init, m_hid, m_out = m_init.to(x.dtype), m_hid.to(x.dtype), m_out.to(x.dtype)
+    h = F.linear(x, sd[p + "initial_layer.weight"] * m_init, sd[p + "initial_layer.bias"])
+    for b in range(op["blocks"]):
+        q = p + f"blocks.{b}.linear_layers."
+        t = F.linear(F.relu(h), sd[q + "0.weight"] * m_hid, sd[q + "0.bias"])
+        t = F.linear(F.relu(t), sd[q + "1.weight"] * m_hid, sd[q + "1.bias"])
+        h = h + t
+    return F.linear(h, sd[p + "final_layer.weight"] * m_out, sd[p + "final_layer.bias"])
+
+
+def rq_spline(x, params, hidden, bins, tail_bound, inverse=False):
+    """Elementwise monotone rational-quadratic spline with linear tails (Durkan et al. 2019, eqs. 4-8; the public code's
+    unconstrained_rational_quadratic_spline).  x: (B, D); params: (B, D, 3 bins - 1).  Returns (y, logabsdet (B, D))."""
+    uw, uh, ud = params[..., :bins] / math.sqrt(hidden), params[..., bins:2 * bins] / math.sqrt(hidden), params[..., 2 * bins:]
+    const = math.log(math.exp(1 - MIN_DERIVATIVE) - 1)
+    ud = F.pad(ud, (1, 1), value=const)                          # boundary derivatives 1: matches the linear tails
+    inside = (x >= -tail_bound) & (x <= tail_bound)
+    xc = x.clamp(-tail_bound, tail_bound)
+    lo, hi = -tail_bound, tail_bound
+
+    def knots(u, minimum):
+        w = minimum + (1 - minimum * bins) * F.softmax(u, dim=-1)
+        c = F.pad(torch.cumsum(w, -1), (1, 0))
+        c = (hi - lo) * c + lo
+        c = torch.cat((torch.full_like(c[..., :1], lo), c[..., 1:-1], torch.full_like(c[..., :1], hi)), -1)
+        return c, c[..., 1:] - c[..., :-1]
+
+    cw, w = knots(uw, MIN_BIN_WIDTH)
+    ch, h = knots(uh, MIN_BIN_HEIGHT)
+    der = MIN_DERIVATIVE + F.softplus(ud)
+    loc = (ch if inverse else cw).clone()
+    loc[..., -1] += 1e-6
+    idx = ((xc[..., None] >= loc).sum(-1) - 1).clamp(0, bins - 1)[..., None]
+    g = lambda t: t.gather(-1, idx)[..., 0]
+    icw, ibw, ich, ih = g(cw), g(w), g(ch), g(h)
+    delta = h / w
+    idelta, d0, d1 = g(delta), g(der), g(der[..., 1:])
+    if inverse:
+        yy = xc - ich
+        a = yy * (d0 + d1 - 2 * idelta) + ih * (idelta - d0)
+        b = ih * d0 - yy * (d0 + d1 - 2 * idelta)
+        c = -idelta * yy
+        root = (2 * c) / (-b - torch.sqrt(b * b - 4 * a * c))
+        out = root * ibw + icw
+        th = root
+    else:
+        th = (xc - icw) / ibw
+    t1 = th * (1 - th)
+    den = idelta + (d0 + d1 - 2 * idelta) * t1
+    if not inverse:
+        out = ich + ih * (idelta * th * th + d0 * t1) / den
+    dnum = idelta * idelta * (d1 * th * th + 2 * idelta * t1 + d0 * (1 - th) * (1 - th))
+    lad = torch.log(dnum) - 2 * torch.log(den)
+    if inverse:
+        lad = -lad
+    return torch.where(inside, out, x), torch.where(inside, lad, torch.zeros_like(lad))
+
+
+def nsf_x_to_z(sd, op, x):
+    """x -> (z, log-jac (B, 1)) of one NSF-prior layer."""
+    k, p = op["kind"], op["prefix"]
+    if k == "rand-channel-perm":                                 # reshaping.py:39-40
+        return x[:, sd[p + "permutation"]], x.new_zeros(x.shape[0], 1)
+    if k == "linear":                                            # linear.py:23-28: y = L (U x) + b
+        L, U, ld = lu_linear_matrices(sd, p)
+        return F.linear(F.linear(x, U), L, sd[p + "linear.bias"]), ld.expand(x.shape[0], 1)
+    params = made_forward(sd, op, x).view(x.shape[0], x.shape[1], -1)      # nsf.py:26-31 -> AutoregressiveTransform.forward
+    z, lad = rq_spline(x, params, op["hidden"], op["bins"], op["tail_bound"])
+    return z, lad.sum(1, keepdim=True)
+
+
+def nsf_z_to_x(sd, op, z):
+    """z -> x of one NSF-prior layer, AS THE REFERENCE'S WRAPPERS DO IT."""
+    k, p = op["kind"], op["prefix"]
+    if k == "rand-channel-perm":                                 # reshaping.py:42-43
+        return z[:, sd[p + "inverse_permutation"]]
+    if k == "linear":
+        # linear.py:30-34 calls self.linear(z) -- the FORWARD map -- in _z_to_x.  Kept: samples drawn through an nsf prior
+        # go through L U z + b here exactly as they do in the reference (the density path x -> z is unaffected).
+        L, U, _ = lu_linear_matrices(sd, p)
+        return F.linear(F.linear(z, U), L, sd[p + "linear.bias"])
+    x = torch.zeros_like(z)                                      # AutoregressiveTransform.inverse: D passes
+    for _ in range(z.shape[1]):
+        params = made_forward(sd, op, x).view(z.shape[0], z.shape[1], -1)
+        x, _ = rq_spline(z, params, op["hidden"], op["bins"], op["tail_bound"], inverse=True)
+    return x
+
+
 # --------------------------------------------------------------------------------------
 # encode  x -> (z_low, low_dim_elbo)      non_square.py:65-66, exact.py:23-30, split.py:15-24
 # --------------------------------------------------------------------------------------
@@ -405,6 +556,9 @@ def encode(sd, flow_ops, base, prior_ops, x):
             ls, sh = sd[op["prefix"] + "log_scale"], sd[op["prefix"] + "shift"]
             u = u * torch.exp(ls) + sh
             lj = lj + ls.sum()
+        elif k in NSF_KINDS:
+            u, l = nsf_x_to_z(sd, op, u)
+            lj = lj + l
         elif k == "gaussian":
             lj = lj + gaussian_log_prob(u)
         else:
@@ -447,6 +601,9 @@ def nested_elbos(sd, ops, y):
             ls, sh = sd[op["prefix"] + "log_scale"], sd[op["prefix"] + "shift"]
             u = u * torch.exp(ls) + sh
             contrib.append(ls.sum().expand(u.shape[0], 1))
+        elif k in NSF_KINDS:
+            u, lj = nsf_x_to_z(sd, op, u)
+            contrib.append(lj)
         elif k == "gaussian":
             contrib.append(gaussian_log_prob(u))
     out, acc = [], 0
@@ -613,6 +770,8 @@ def prior_inverse(sd, prior_ops, u):
             u = acl_z_to_x(sd, op, u)
         elif k == "affine":
             u = (u - sd[op["prefix"] + "shift"]) * torch.exp(-sd[op["prefix"] + "log_scale"])
+        elif k in NSF_KINDS:
+            u = nsf_z_to_x(sd, op, u)
     return u
 
 

@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 
 from conftest import COND, FULL, SMALL
 ALL = SMALL + COND + FULL
+#: end-to-end tolerance on J / J^T J / log-det where the fixture point is within rounding of a relu kink (see the test)
+END_TO_END_TOL = {"mini_mnist_cond1e3": 3e-3}
 
 
 def rel(a, b, floor=1e-9):
@@ -70,19 +72,34 @@ def test_parts_match_reference_vectors(name):
         assert rel(z_low, g["z_low"]) < 1e-5
         assert rel(low_elbo.view(-1, 1), g["low_dim_elbo"]) < 1e-5
         assert rel(earliest, g["earliest_latent"]) < 1e-5
+        # decode side at the REFERENCE's latent: Jacobian, Gram, Cholesky with no encode rounding in between
+        from cmf_amd import engine as E
+        d = g["jtj"].shape[1]
+        x_hat, T = head.program.decode(g["z_low"].cuda(), tangents=True)
+        assert rel(x_hat, g["x_hat"]) < 1e-5
+        if "J" in g:
+            assert rel(T.to_dense(d), g["J"]) < 1e-4
+        gf = E.gram_cholesky(T, d)
+        assert rel(gf.jtj, g["jtj"]) < 1e-4 and rel(gf.logdet.view(-1, 1), g["logdet"]) < 1e-4
+        # end to end (HIP encode -> decode -> Gram -> Cholesky).  One fixture sits on a relu kink: the ORACLE's own J / log-det
+        # / g_ij of mini_mnist_cond1e3 jump by 7.0e-4 / 3.2e-4 / 1.9e-3 when its z_low moves by 1e-6 relative (a few ulps, the rounding of
+        # any fp32 encode chain; tests/test_oracle_golden.py::test_relu_kink_next_to_the_cond1e3_fixture), and the HIP
+        # encode lands on the other side of it (z_low agrees to 6e-6 of max |z| = 4829).  Every other fixture: 1e-4.
+        tol = END_TO_END_TOL.get(name, 1e-4)
         x_hat, J = head.jacobian(z_low)
         assert rel(x_hat, g["x_hat"]) < 1e-5
         if "J" in g:
-            assert rel(J, g["J"]) < 1e-4
+            assert rel(J, g["J"]) < tol
         head.elbo(y, add_offdiagonal_metric_reg=True)
         gr = head.last_gram
-        assert rel(gr.jtj, g["jtj"]) < 1e-4
-        assert rel(gr.logdet.view(-1, 1), g["logdet"]) < 1e-4           # log-det itself, 1e-4 relative
+        assert rel(gr.jtj, g["jtj"]) < tol
+        assert rel(gr.logdet.view(-1, 1), g["logdet"]) < tol             # log-det itself, 1e-4 relative
         assert gr.attempts == 1 and int(gr.info.abs().max()) == 0
         d = g["jtj"].shape[1]
         off = g["jtj"].abs().sum((1, 2)) - torch.diagonal(g["jtj"], dim1=1, dim2=2).abs().sum(1)
-        assert rel(gr.l1_off, off) < 1e-4                                 # g_ij loss
-        assert rel(gr.l1_diag, torch.diagonal(g["jtj"], dim1=1, dim2=2).abs().sum(1)) < 1e-4
+        assert rel(gr.l1_off, off) < tol                                  # g_ij loss
+        assert rel(gf.l1_off, off) < 1e-4
+        assert rel(gr.l1_diag, torch.diagonal(g["jtj"], dim1=1, dim2=2).abs().sum(1)) < tol
         # likelihood term = low_dim_elbo - logdet/2 (the "log-prob" of the north star)
         lik = low_elbo.cpu().view(-1, 1) - gr.logdet.cpu().view(-1, 1) / 2
         assert rel(lik, g["low_dim_elbo"] - g["logdet"] / 2) < 1e-4

@@ -352,3 +352,64 @@ def test_two_devices_one_process():
     for t in threads:
         t.join()
     assert rel(outs[0], outs[1]) < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# f3: NSF prior (parity unpinned; HIP kernels vs the oracle's restatement of the published algorithm)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("dataset,layers,hidden", [("power", 2, (16, 16)), ("hepmass", 3, (32, 32)), ("miniboone", 1, (8,))])
+def test_nsf_prior_elbo_latents_and_samples_match_the_oracle(dataset, layers, hidden):
+    """``prior: "nsf"`` (schemas.py:87-103): rand-channel-perm + LULinear + masked autoregressive rational-quadratic spline
+    layers under the tail.  elbo, low-dim elbo, earliest latent and fixed samples of the HIP path against the float64 oracle
+    restatement (cmf_rq_spline / cmf_lu_weights / cmf_made_mask_weight + the linear layers on cmf_conv_primal)."""
+    from test_oracle_golden import nsf_model
+    from oracle import cmf_oracle as O
+    cfg, schema, shape, dens, sd, sdo, ops = nsf_model(dataset, layers, hidden)
+    dens = dens.cuda().eval()
+    head = find_head(dens)
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(16, *shape, generator=gen) * 1.5
+    if dataset == "sphere":
+        x = x / x.norm(dim=1, keepdim=True)
+    with torch.no_grad():
+        want = O.elbo(sdo, ops, x.double(), add_offdiagonal_metric_reg=True, return_parts=True)
+        got = dens.elbo(x.cuda(), add_offdiagonal_metric_reg=True)
+        assert rel(got["elbo"], want["elbo"]) < 1e-4
+        z_low, low, earliest = head.program.encode(x.cuda())
+        assert rel(low.view(-1, 1), want["parts"]["low_dim_elbo"]) < 1e-4
+        assert rel(earliest, O.extract_latent(sdo, ops, x.double(), earliest_latent=True)) < 1e-4
+        noise = torch.randn(8, cfg["latent_dimension"], generator=gen) * 1.3
+        assert rel(dens.fixed_sample(noise.cuda()), O.fixed_sample(sdo, ops, noise.double())) < 1e-4
+        head.nested_prior_dict = True
+        nested = dens.elbo(x.cuda(), add_offdiagonal_metric_reg=True)["prior-dict"]
+        levels = O.nested_elbos(sdo, ops, x.double())
+        node, i = nested, 0
+        while isinstance(node, dict):
+            assert rel(node["elbo"], levels[i]) < 1e-4, i
+            node, i = node.get("prior-dict"), i + 1
+        assert i == len(levels)
+    dens.train()
+    with pytest.raises(NotImplementedError, match="nsf prior"):
+        with torch.enable_grad():
+            dens.elbo(x.cuda())
+
+
+def test_rq_spline_kernel_inverse_and_tails():
+    from cmf_amd import engine as E
+    from oracle import cmf_oracle as O
+    gen = torch.Generator().manual_seed(4)
+    B, D, bins, hidden = 33, 10, 8, 32
+    x = torch.randn(B, D, generator=gen) * 2.5
+    x[0, 0], x[0, 1], x[1, 0] = 3.0, -3.0, 0.0                       # the tail bound itself and the middle knot region
+    params = torch.randn(B, D * (3 * bins - 1), generator=gen) * 2
+    lj = torch.zeros(B, device="cuda")
+    z = E.rq_spline(x.cuda(), params.cuda(), bins, hidden, 3.0, lj=lj)
+    zw, lw = O.rq_spline(x.double(), params.double().view(B, D, -1), hidden, bins, 3.0)
+    assert rel(z, zw) < 1e-5 and rel(lj, lw.sum(1)) < 1e-4
+    outside = x.abs() > 3
+    assert torch.equal(z.cpu()[outside], x[outside]) and bool(outside.any())
+    lji = torch.zeros(B, device="cuda")
+    xr = E.rq_spline(z, params.cuda(), bins, hidden, 3.0, inverse=True, lj=lji)
+    assert rel(xr, x) < 1e-5 and float((lj + lji).abs().max()) < 1e-3

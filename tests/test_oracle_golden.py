@@ -152,6 +152,36 @@ def test_one_ulp_input_sensitivity_of_the_oracle():
     assert float(d_ld.median()) < 1e-4
 
 
+def test_relu_kink_next_to_the_cond1e3_fixture():
+    """Reference-side yardstick for the one widened end-to-end tolerance of tests/test_gpu_parity.py: move the ORACLE's own
+    z_low of mini_mnist_cond1e3 by 1e-6 relative per component (a few ulps -- what the rounding of any fp32 encode chain
+    does) and its own J / log-det JUMP by ~7e-4 / ~3e-4: one sample sits within rounding of a relu kink of the decoder.
+    The cond ~ 1e2 sibling moves by < 1e-5 under the same perturbations."""
+    def spread(name):
+        g, meta = load_golden(name)
+        cfg, schema, x_shape, ops, sd = golden_model(meta)
+        pre, head, flow_ops, base, prior_ops = O.split_ops(ops)
+        z = g["z_low"]
+        gen = torch.Generator().manual_seed(0)
+        with torch.no_grad():
+            jtj0, _, J0 = O.jtj_batched(sd, flow_ops, base, z)
+            ld0 = O.cholesky_logdet(jtj0)[0]
+            l10 = O.metric_l1(jtj0, False)
+            dJ, dld, dl1 = [], [], []
+            for _ in range(30):
+                zz = z + z * torch.randn(z.shape, generator=gen) * 1e-6
+                jtj, _, J = O.jtj_batched(sd, flow_ops, base, zz)
+                dJ.append(rel(J, J0))
+                dld.append(rel(O.cholesky_logdet(jtj)[0], ld0))
+                dl1.append(rel(O.metric_l1(jtj, False), l10))
+        return max(dJ), max(dld), sorted(dJ)[len(dJ) // 2], max(dl1)
+    jmax, ldmax, jmed, l1max = spread("mini_mnist_cond1e3")
+    print(f"oracle under 1e-6 relative z perturbations: J max {jmax:.1e} median {jmed:.1e}, log-det max {ldmax:.1e}, g_ij max {l1max:.1e}")
+    assert jmax > 3e-4 and ldmax > 1e-4 and l1max > 1e-3 and jmed < 2e-5, (jmax, ldmax, jmed, l1max)    # a jump, not a slope
+    jmax2, ldmax2, _, l1max2 = spread("mini_mnist_cond1e2")
+    assert jmax2 < 1e-5 and ldmax2 < 1e-5 and l1max2 < 1e-5
+
+
 def test_known_answers_square_case():
     """d == D (sphere, d=3): -1/2 logdet(J^T J) == -log|det J|, and the hand-written tangents agree with autograd."""
     g, meta = load_golden("c1_sphere")
@@ -187,3 +217,84 @@ def test_cholesky_jitter_retry_semantics():
     logdet, Gj, attempts = O.cholesky_logdet(G)
     assert attempts >= 2
     assert torch.allclose(Gj[0], (1 + 1e-6 * sum(10 ** k for k in range(attempts - 1))) * torch.eye(3), atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# NSF prior (parity unpinned: jrmcornish/nsf is not vendored): invariants of the restatement
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def nsf_model(dataset="power", layers=2, hidden=(16, 16), seed=0, dtype=torch.float64):
+    import cmf_amd
+    from cmf_amd.recipe import fill_state_dict
+    cfg = cmf_amd.get_config(dataset, prior="nsf", prior_num_density_layers=layers, prior_hidden_channels=list(hidden))
+    schema = cmf_amd.get_schema(cfg)
+    shape = cmf_amd.DATA_SHAPES[dataset]
+    dens = cmf_amd.get_density(schema, torch.zeros(1, *shape))
+    sd = fill_state_dict(dens.state_dict(), seed=seed)
+    dens.load_state_dict(sd)
+    ops = O.compile_schema(schema, shape)
+    sdo = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+    return cfg, schema, shape, dens, sd, sdo, ops
+
+
+def test_nsf_prior_layers_are_invertible_with_the_right_log_jacobian():
+    """Every nsf prior layer of the restatement: z_to_x(x_to_z(x)) = x (except LULinear, whose reference wrapper applies the
+    FORWARD map in z_to_x, bijections/linear.py:30-34) and log-jac = log |det| of the autograd Jacobian; the spline layer's
+    Jacobian is lower triangular (the MADE masks are autoregressive)."""
+    cfg, schema, shape, dens, sd, sdo, ops = nsf_model("hepmass")          # d = 10
+    pre, head, flow_ops, base, prior_ops = O.split_ops(ops)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(4, cfg["latent_dimension"], generator=gen, dtype=torch.float64) * 2.5      # some values beyond the tail bound 3
+    kinds = []
+    for op in prior_ops:
+        if op["kind"] not in O.NSF_KINDS:
+            continue
+        kinds.append(op["kind"])
+        z, lj = O.nsf_x_to_z(sdo, op, x)
+        J = torch.autograd.functional.jacobian(lambda t: O.nsf_x_to_z(sdo, op, t[None])[0][0], x[0])
+        assert abs(float(torch.linalg.slogdet(J)[1]) - float(lj[0])) < 1e-9
+        if op["kind"] == "nsf-ar":
+            assert float(torch.triu(J, 1).abs().max()) == 0.0
+            assert float((O.nsf_z_to_x(sdo, op, z) - x).abs().max()) < 1e-9
+        elif op["kind"] == "rand-channel-perm":
+            assert torch.equal(O.nsf_z_to_x(sdo, op, z), x)
+        else:
+            L, U, _ = O.lu_linear_matrices(sdo, op["prefix"])
+            assert torch.allclose(O.nsf_z_to_x(sdo, op, x), x @ (L @ U).T + sdo[op["prefix"] + "linear.bias"])
+        x = z
+    assert kinds == ["rand-channel-perm", "linear", "nsf-ar"] * 2 + ["rand-channel-perm", "linear"]
+
+
+def test_nsf_prior_elbo_is_a_density_in_the_latent_space():
+    """low_dim_elbo of the nsf prior = log N(u) + sum log-jac: its exponential integrates to 1 over the latent (d = 2,
+    quadrature) -- the change-of-variables bookkeeping of the whole prior chain."""
+    cfg, schema, shape, dens, sd, sdo, ops = nsf_model("power")              # d = 2
+    pre, head, flow_ops, base, prior_ops = O.split_ops(ops)
+    n = 401
+    t = torch.linspace(-9, 9, n, dtype=torch.float64)
+    grid = torch.stack(torch.meshgrid(t, t, indexing="ij"), -1).reshape(-1, 2)
+    u, lj = grid, torch.zeros(grid.shape[0], 1, dtype=torch.float64)
+    for op in prior_ops:
+        if op["kind"] in O.NSF_KINDS:
+            u, l = O.nsf_x_to_z(sdo, op, u)
+            lj = lj + l
+    logp = lj + O.gaussian_log_prob(u)
+    mass = float(torch.exp(logp).sum() * (t[1] - t[0]) ** 2)
+    assert abs(mass - 1.0) < 2e-3, mass
+
+
+def test_nsf_state_dict_schema():
+    """Names of the nsf code base's modules / parameters (LULinear, MADE with masked residual blocks), as the reference's
+    checkpoints carry them."""
+    cfg, schema, shape, dens, sd, sdo, ops = nsf_model("power", layers=1, hidden=(8,))
+    keys = [k.split("bijection.", 1)[1] for k in sd if "bijection." in k and ("linear." in k or "flow." in k or "permutation" in k)]
+    assert keys[:2] == ["permutation", "inverse_permutation"]
+    assert keys[2:6] == ["linear.bias", "linear.lower_entries", "linear.upper_entries", "linear.unconstrained_upper_diag"]
+    net = [k for k in keys if k.startswith("flow.autoregressive_net.")]
+    assert net[:4] == [f"flow.autoregressive_net.initial_layer.{n}" for n in ("weight", "bias", "mask", "degrees")]
+    assert "flow.autoregressive_net.blocks.0.linear_layers.1.weight" in net and net[-1] == "flow.autoregressive_net.final_layer.degrees"
+    mades = [m for m in dens.modules() if type(m).__name__ == "_MADE"]
+    m_init, m_hid, m_out = O.made_masks(2, 8, 23)
+    assert torch.equal(mades[0].initial_layer.mask, m_init) and torch.equal(mades[0].final_layer.mask, m_out)
+    assert torch.equal(mades[0].blocks[0].linear_layers[0].mask, m_hid)
