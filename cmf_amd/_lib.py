@@ -66,6 +66,8 @@ SIGNATURES = {
     "cmf_cholesky_retry": (_i, [_fp, _i, _i, _i, _f, _fp, _fp, _fp, _fp, _fp]),
     "cmf_stanh_backward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
     "cmf_tanh_cross_terms": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _fp, _fp, _i, _i, _i, _fp]),
+    "cmf_tanh_backward": (_i, [_fp, _fp, _fp, _ll, _fp, _fp]),
+    "cmf_affine_prior_backward": (_i, [_fp, _ll, _fp, _ll, _fp, _i, _i, _fp, _fp, _fp, _fp]),
     "cmf_accumulate": (_i, [_fp, _fp, _ll, _fp]),
     "cmf_relu_bits": (_i, [_fp, _fp, _i, _i, _i, _fp]),
     "cmf_channel_sum": (_i, [_fp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _fp, _fp]),

@@ -98,7 +98,58 @@ __global__ __launch_bounds__(256) void relu_bits_kernel(const float* __restrict_
   out[(b * HW + px) * noct + oct] = (unsigned char)bits;
 }
 
+// MLP coupler primal backward, elementwise stage (networks.py:206-224: h = tanh(W h' + b)): the cotangent of a hidden
+// layer's pre-activation from the cotangent of its output, d = (dh + extra) (1 - a^2), a = the tanh output; `extra` (may be
+// NULL) is the second-order term the tangent pass adds to dh (cmf_tanh_cross_terms).  Flat over n elements, any layout.
+__global__ void tanh_backward_kernel(const float* __restrict__ dh, const float* __restrict__ a, const float* __restrict__ extra,
+                                     long long n, float* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float av = a[i], e = extra ? extra[i] : 0.f;
+    out[i] = (dh[i] + e) * (1.f - av * av);
+  }
+}
+
+// AffineBijection backward (affine.py:24-34, u = x e^{ls} + sh, log-jac = sum ls): per feature f (one thread each, the
+// batch loop reads coalesced across features)  g_ls[f] += sum_b dz x e^{ls} + sum_b dlj[b],  g_sh[f] += sum_b dz,
+// dz <- dz e^{ls} in place.
+__global__ void affine_prior_backward_kernel(float* __restrict__ dz, long long dz_b, const float* __restrict__ x, long long x_b,
+                                             const float* __restrict__ log_scale, int n, int B, const float* __restrict__ dlj,
+                                             float* __restrict__ g_ls, float* __restrict__ g_sh) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const float es = expf(log_scale[f]);
+  float als = 0.f, ash = 0.f, alj = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = dz[b * dz_b + f];
+    als += d * x[b * x_b + f] * es;
+    ash += d;
+    if (dlj) alj += dlj[b];
+    dz[b * dz_b + f] = d * es;
+  }
+  g_ls[f] += als + alj;
+  g_sh[f] += ash;
+}
+
 }  // namespace
+
+extern "C" int cmf_tanh_backward(const float* dh, const float* a, const float* extra, long long n, float* out, void* stream) {
+  if (!dh || !a || !out || n <= 0) return CMF_EINVAL;
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(tanh_backward_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, (hipStream_t)stream,
+                     dh, a, extra, n, out);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cmf_affine_prior_backward(float* dz, long long dz_b, const float* x, long long x_b, const float* log_scale, int n,
+                                         int B, const float* dlj, float* g_ls, float* g_sh, void* stream) {
+  if (!dz || !x || !log_scale || !g_ls || !g_sh || n <= 0 || B <= 0) return CMF_EINVAL;
+  hipLaunchKernelGGL(affine_prior_backward_kernel, dim3(cmf_ceil_div(n, 64)), dim3(64), 0, (hipStream_t)stream, dz, dz_b, x, x_b,
+                     log_scale, n, B, dlj, g_ls, g_sh);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int cmf_stanh_backward(const float* dy, const float* dg, const float* y, const float* g, const float* sw,
                                   const float* sb, float* du, float* dsw, float* dsb, int B, int C, int HW, void* stream) {

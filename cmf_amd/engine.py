@@ -1015,23 +1015,41 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
 
 
 def mlp_primal_backward(net, z, view, acts, dy, grads, dz, dh_extra=None):
-    """Primal backward of an MLP coupler network (the low-dimensional prior flows: d = 64 inputs, 32-wide layers): plain small
-    GEMMs, so they go to the BLAS library (torch.mm -> rocBLAS) with elementwise tanh' in between.  ``acts`` = the tanh outputs
-    ``net_primal`` returned; accumulates weight / bias gradients into ``grads`` and the input cotangent into ``dz``."""
+    """Primal backward of an MLP coupler network (2-D / tabular couplers and every low-dimensional prior flow) on the same
+    kernels as the ResNet path: 16 samples ride in the 16 column slots of the tangent-conv kernels (``cmf_primal_regroup``), so
+    per layer  dW += sum d (x) h  is ``cmf_conv_tangent_wgrad`` with taps = 1,  db  is ``cmf_channel_sum``,  W^T d  is
+    ``cmf_conv_tangent`` on the transposed pack, and the tanh stage  d = (dh + extra) (1 - a^2)  is ``cmf_tanh_backward``.
+    ``acts`` = the tanh outputs ``net_primal`` returned; ``dh_extra`` = the tangent pass's second-order terms
+    (``net_cotangent(cross=)``).  Accumulates weight / bias gradients into ``grads`` and the input cotangent into ``dz``."""
     assert net.kind == "mlp" and view.mask is None
     lins = [m for m in net if isinstance(m, nn.Linear)]
-    B = z.shape[0]
+    B, dev = z.shape[0], z.device
+    Bp = (B + 15) // 16 * 16
+    G = Bp // 16
+
+    def grp(t):                                            # (B, F) -> flat grouped (G, F, 16), zero-padded samples
+        t = t.reshape(B, -1)
+        if Bp != B:
+            t = torch.cat([t, torch.zeros(Bp - B, t.shape[1], dtype=t.dtype, device=dev)])
+        return primal_regroup(t.contiguous(), True)
+
+    # a grouped tensor (G, c, 16) as ONE image row of G "pixels" (the call shape of the MLP tangent pass): (np, chan, px) strides
+    pn = lambda c: (0, 16, c * 16)
     rows = z.reshape(B, -1)[:, view.chan_off::view.chan_step][:, :view.cin]
-    hs = [rows] + list(acts)                                # input of every linear layer
-    d = dy.reshape(B, -1)
+    hs = [grp(rows)] + [grp(a) for a in acts]              # input of every linear layer, grouped
+    d_g = grp(dy.reshape(B, -1))
+    lib = _lib.load()
     for i in reversed(range(len(lins))):
         lin = lins[i]
-        _grad_of(grads, lin.weight).addmm_(d.t(), hs[i])
-        _grad_of(grads, lin.bias).add_(d.sum(0))
-        dh = d @ lin.weight.detach()
+        cin, cout = lin.in_features, lin.out_features
+        conv_tangent_wgrad(hs[i], 0, *pn(cin), d_g, 0, *pn(cout), _grad_of(grads, lin.weight), 1, 1, cin, cout, 1, G, 16)
+        channel_sum(d_g, *pn(cout), 1, cout, G, 16, _grad_of(grads, lin.bias))
+        dh_g = torch.empty(G * cin * 16, dtype=torch.float32, device=dev)
+        conv_tangent(d_g, 0, *pn(cout), lin.weight, 1, dh_g, *pn(cin), 1, cout, cin, 1, G, 16, transpose=True, precision="f32")
         if i > 0:
-            if dh_extra is not None and (i - 1) in dh_extra:            # second-order term of the tangent pass (net_cotangent)
-                dh = dh + dh_extra[i - 1]
-            d = dh * (1.0 - acts[i - 1] * acts[i - 1])
+            extra = grp(dh_extra[i - 1]) if dh_extra is not None and (i - 1) in dh_extra else None
+            _lib.check(lib.cmf_tanh_backward(_p(dh_g), _p(hs[i]), _p(extra), dh_g.numel(), _p(dh_g), _stream()), "cmf_tanh_backward")
+            d_g = dh_g
         else:
+            dh = primal_regroup(dh_g.view(G, -1), False).view(Bp, cin)[:B]
             dz.reshape(B, -1)[:, view.chan_off::view.chan_step][:, :view.cin] += dh

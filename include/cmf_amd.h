@@ -307,6 +307,13 @@ int cmf_stanh_backward(const float* dy, const float* dg, const float* y, const f
  *     c <- phi c  (in place: the cotangent of layer i's raw output);   dh[b][f] += -2 h sum_col c_old x                    */
 int cmf_tanh_cross_terms(float* c, long long c_b, long long c_r, const float* x, long long x_b, long long x_r,
                          const float* h, float* dh, int F, int B, int nc, void* stream);
+/* MLP coupler primal backward, elementwise stage (networks.py:206-224): out = (dh + extra) (1 - a^2) over n floats, a = the
+ * tanh output, extra (or NULL) = the tangent pass's second-order term (cmf_tanh_cross_terms).  out may alias dh.          */
+int cmf_tanh_backward(const float* dh, const float* a, const float* extra, long long n, float* out, void* stream);
+/* AffineBijection backward (affine.py:24-34): g_ls[f] += sum_b dz x e^{ls} + sum_b dlj[b] (dlj may be NULL), g_sh[f] += sum_b dz,
+ * dz <- dz e^{ls} in place; dz, x: (B, n) with row strides dz_b, x_b.                                                     */
+int cmf_affine_prior_backward(float* dz, long long dz_b, const float* x, long long x_b, const float* log_scale, int n, int B,
+                              const float* dlj, float* g_ls, float* g_sh, void* stream);
 /* dst[i] += src[i], n % 4 == 0, 16-byte aligned: the skip connection of the reverse sweep next to the split-precision kernel. */
 int cmf_accumulate(float* dst, const float* src, long long n, void* stream);
 /* relu' bit mask of an activation tensor act (B, C, HW), C % 8 == 0, in the CMF_F_RELU_BITS layout: out[B][HW][C/8] bytes,

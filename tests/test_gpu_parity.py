@@ -400,7 +400,10 @@ def test_parity_statistics_full_mnist_model():
     """32 fresh MNIST-sized inputs through the full d = 64 model against the CPU oracle (about half a minute of CPU):
     the batch-mean loss terms -- what the 1e-4 tolerance of SURVEY 8d is about -- and the per-sample medians.  A single
     sample may sit on a relu kink (a pre-activation within rounding of zero flips a mask and moves that sample's J by
-    ~1e-4 in ANY fp32 implementation), so the per-sample maximum gets a looser bound."""
+    ~1e-4 in ANY fp32 implementation), so the per-sample maximum gets a looser bound.  The bound is the
+    reference arithmetic's own yardstick: on THIS 32-sample set the CPU oracle's per-sample log-det / g_ij move by up to
+    4.2e-5 / 1.7e-4 (medians 1.1e-6 / 1.9e-6) when its input moves by ONE float32 ulp (tests/dev/one_ulp_full.py,
+    profiles/r02_oracle_one_ulp_full_size.txt); the HIP path's worst samples are at 4.5e-5 / 2.1e-4."""
     import cmf_amd
     from cmf_amd.recipe import fill_state_dict
     from oracle import cmf_oracle as O
@@ -426,7 +429,7 @@ def test_parity_statistics_full_mnist_model():
         e = per(a, b)
         assert mean_rel(a, b) < 2e-5, (name, "batch mean", mean_rel(a, b))
         assert float(e.median()) < 5e-6, (name, "median", float(e.median()))
-        assert float(e.max()) < 1e-3, (name, "max", float(e.max()))
+        assert float(e.max()) < 5e-4, (name, "max", float(e.max()))
 
 
 @pytest.mark.parametrize("name", ["mini_mnist", "mini_cifar", "c2b_hepmass", "c1_sphere"])

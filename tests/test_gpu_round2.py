@@ -413,3 +413,53 @@ def test_rq_spline_kernel_inverse_and_tails():
     lji = torch.zeros(B, device="cuda")
     xr = E.rq_spline(z, params.cuda(), bins, hidden, 3.0, inverse=True, lj=lji)
     assert rel(xr, x) < 1e-5 and float((lj + lji).abs().max()) < 1e-3
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# C5 at full size: CIFAR-shaped D = 3072, d = 128, default 64 x 8 ResNet couplers, the per-GPU shard of 32 samples
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def test_full_size_c5_properties():
+    """BASELINE configs[4] at its full size on one GPU's shard (32 of 256 samples), where the reference-generated fixture
+    ``c5_cifar_full`` (B = 2; in test_gpu_parity's fixture lists) pins the values and these size-independent properties
+    cover the batch:
+      * shard invariance of the eval-mode (exact) elbo;
+      * the fused kernel's log-det = fp64 slogdet of the Gram matrix it returned (d = 128: the NT = 8 kernel);
+      * train mode, ``hutch_with_cg`` with S = 4 probes (the configuration's stochastic log-det): with CG run to convergence
+        the surrogate value is mean_s |eps_s|^2 (u = (J^T J)^-1 eps, so u^T (J^T J) eps = eps^T eps), and J^T J eps from the
+        kernel equals the returned Gram matrix applied to the probes;
+      * the default CG budget (max_cg_iterations = d, tolerance 1: gpytorch's rule stops after 11 iterations) runs and
+        returns finite values -- its iterates are parity-unpinned."""
+    import cmf_amd
+    from cmf_amd.recipe import fill_state_dict
+    cfg = cmf_amd.get_config("cifar10", latent_dimension=128, hutchinson_samples=4)
+    assert cfg["log_jacobian_method"] == "hutch_with_cg"
+    B, shape = 32, cmf_amd.DATA_SHAPES["cifar10"]
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randint(0, 256, (B, *shape), generator=gen).float() + torch.rand(B, *shape, generator=gen)
+    dens = cmf_amd.get_density(cmf_amd.get_schema(cfg), x[:2])
+    dens.load_state_dict(fill_state_dict(dens.state_dict(), seed=0), strict=True)
+    dens = dens.cuda().eval()
+    core, head = inner(dens, True), find_head(dens)
+    xg = x.cuda()
+    with torch.no_grad():
+        out = core.elbo(xg.clone(), add_reconstruction=True)["elbo"]            # eval mode: the exact path (non_square.py:131-134)
+        gram = head.last_gram
+        assert out.shape == (B, 1) and bool(torch.isfinite(out).all()) and gram.jtj.shape == (B, 128, 128)
+        sign, want_ld = torch.linalg.slogdet(gram.jtj.double())
+        assert bool((sign > 0).all()) and rel(gram.logdet.double(), want_ld) < 1e-5
+        part = core.elbo(xg[8:24].clone(), add_reconstruction=True)["elbo"]
+        assert rel(part, out[8:24]) < 1e-5
+        # train mode: Hutchinson + CG
+        dens.train()
+        head.max_cg_iterations, head.cg_tolerance = 4 * 128, 1e-7
+        tr = core.elbo(xg.clone(), add_reconstruction=True)["elbo"]
+        h = head.last_hutchinson
+        assert h["eps"].shape == (B, 128, 4)
+        assert rel(h["w"], torch.bmm(head.last_gram.jtj.double(), h["eps"].double())) < 1e-5
+        assert rel(h["value"], (h["eps"].double() ** 2).sum(1).mean(1)) < 2e-3
+        assert bool(torch.isfinite(tr).all())
+        head.max_cg_iterations, head.cg_tolerance = 128, 1
+        tr2 = core.elbo(xg.clone(), add_reconstruction=True)["elbo"]
+        assert bool(torch.isfinite(tr2).all()) and int(head.last_hutchinson["iterations"].max()) == 11
