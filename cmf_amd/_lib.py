@@ -41,6 +41,16 @@ class ConvPrimalArgs(C.Structure):
                 ("B", _i), ("cin", _i), ("cout", _i), ("H", _i), ("W", _i), ("taps", _i)]
 
 
+MLP_MAX_LAYERS = 8
+
+
+class MlpCouplerArgs(C.Structure):
+    _fields_ = [("z", _fp), ("z_b", _ll), ("t", _fp), ("t_f", _ll), ("w", _fp),
+                ("zi", _fp), ("si", _fp), ("ti", _fp), ("n_mod", _i),
+                ("B", _i), ("cin", _i), ("chan_off", _i), ("chan_step", _i), ("n_layers", _i),
+                ("width", _i * (MLP_MAX_LAYERS + 1)), ("w_off", _ll * MLP_MAX_LAYERS), ("decode", _i), ("lj", _fp)]
+
+
 #: every symbol include/cmf_amd.h declares -> (restype, argtypes)
 SIGNATURES = {
     "cmf_version": (C.c_char_p, []),
@@ -82,6 +92,9 @@ SIGNATURES = {
     "cmf_recon_sqerr": (_i, [_fp, _fp, _i, _i, _fp, _fp]),
     "cmf_elbo_combine": (_i, [_fp, _fp, _fp, _fp, _fp, _f, _f, _f, _i, _fp, _fp]),
     "cmf_hutch_cg": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _fp, _fp]),
+    "cmf_mlp_coupler": (_i, [C.POINTER(MlpCouplerArgs), _fp]),
+    "cmf_pack_mlp_layer": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp, C.POINTER(_ll), _fp]),
+    "cmf_mlp_hidden_tiles": (_i, [_i]),
     "cmf_rq_spline": (_i, [_fp, _ll, _fp, _i, _i, _i, _f, _i, _i, _fp, _ll, _fp, _fp]),
     "cmf_lu_weights": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp]),
     "cmf_made_mask_weight": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp]),

@@ -129,11 +129,17 @@ class AffineCouplingBijection(Bijection):
 
     # engine-level steps (in place on z / T) ----------------------------------------------------
     def encode_(self, z, lj=None):
-        y, _, _ = E.net_primal(self.net, z, self.view(z.device), need_acts=False)
+        view = self.view(z.device)
+        if E.mlp_coupler_supported(self.net, view, None, 2 * self.cmod):      # the whole layer in one launch
+            return E.mlp_coupler(self.net, z, None, view, self.maps(z.device), decode=False, lj=lj)
+        y, _, _ = E.net_primal(self.net, z, view, need_acts=False)
         E.acl_primal(z, y, self.maps(z.device), decode=False, lj=lj)
 
-    def decode_(self, z, T=None, lj=None):
+    def decode_(self, z, T=None, lj=None, ncols=None):
         view = self.view(z.device)
+        if ((T is None or (ncols is not None and ncols <= 15 and lj is None))
+                and E.mlp_coupler_supported(self.net, view, T, 2 * self.cmod)):
+            return E.mlp_coupler(self.net, z, T, view, self.maps(z.device), decode=True, lj=lj, ncols=ncols)
         # the split-precision tangent pass reads relu' from bit masks written by the primal pass (engine.BitMask)
         want = False if T is None else ("bits" if E.TANGENT_PRECISION == "bf16x3" else True)
         y, g, acts = E.net_primal(self.net, z, view, need_acts=want)
@@ -248,7 +254,7 @@ class AffineCouplingBijection(Bijection):
         E.require_gpu(z)
         x = z.detach().clone().contiguous()
         T = self._wrap_tangent(v.detach(), self.layout)
-        self.decode_(x, T)
+        self.decode_(x, T, ncols=1)
         return {"x": x, "jvp": self._unwrap_tangent(T, self.x_shape)}
 
 

@@ -419,13 +419,13 @@ class FlowProgram:
         N = int(np.prod(self.tail.x_shape))
         scatter = self.tail.scatter_index(dev)
         z = E.gather_primal(z_low.contiguous(), scatter, N).view(B, *self.tail.x_shape)
-        T = None
+        T, ncols = None, None
         if tangents:
             ncols = self.d if eps is None else eps.shape[2]
             T = E.seed_tangent(B, N, E.ceil16(ncols), self.layout, scatter, self.d, dev, eps=eps)
         for m in reversed(self.layers):
             if isinstance(m, AffineCouplingBijection):
-                m.decode_(z, T)
+                m.decode_(z, T, ncols=ncols)
             elif isinstance(m, SplitDensity):
                 n = z[0].numel()                 # zero-pad the dropped half (split.py:50-52)
                 idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),

@@ -538,6 +538,84 @@ class _DerivedCache:
 DERIVED = _DerivedCache()
 
 
+#: fused coupling layers for MLP couplers (cmf_mlp_coupler): False = always the per-layer launches (the training path
+#: always uses them: it needs every layer's state)
+FUSED_MLP = True
+
+
+def mlp_coupler_supported(net, view, T, n_out):
+    """Shapes the fused kernel covers: tanh MLP, <= 8 linear layers, hidden <= 128, outputs <= 64, inputs <= 128; with
+    tangents: 16 column slots of which at most 15 are Jacobian columns (column 15 carries the primal)."""
+    if not FUSED_MLP or net.kind != "mlp" or view.mask is not None:
+        return False
+    lins = [m for m in net if isinstance(m, nn.Linear)]
+    if not 2 <= len(lins) <= _lib.MLP_MAX_LAYERS or view.cin > 128 or n_out > 64:
+        return False
+    if any(l.out_features > 128 for l in lins[:-1]):
+        return False
+    return T is None or (T.layout == "fmajor" and T.nc == 16)
+
+
+def _mlp_images(net):
+    """All layer images of an MLP coupler net back to back (cmf_pack_mlp_layer), cached per parameter version:
+    (flat tensor, float offsets, widths)."""
+    lins = [m for m in net if isinstance(m, nn.Linear)]
+    params = [p for l in lins for p in (l.weight, l.bias)]
+
+    def build():
+        lib = _lib.load()
+        ht = lib.cmf_mlp_hidden_tiles(max(l.out_features for l in lins[:-1]))
+        tiles = [(ht if i + 1 < len(lins) else (l.out_features + 15) // 16, ht if i > 0 else (l.in_features + 15) // 16)
+                 for i, l in enumerate(lins)]                    # (output tiles, input K groups) per layer
+        sizes = []
+        for l, (mt, kg) in zip(lins, tiles):
+            n = C.c_longlong(0)
+            _lib.check(lib.cmf_pack_mlp_layer(None, None, l.out_features, l.in_features, 0, mt, kg, None, C.byref(n), None), "pack size")
+            sizes.append((n.value + 3) // 4 * 4)
+        offs = [0]
+        for n in sizes[:-1]:
+            offs.append(offs[-1] + n)
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=lins[0].weight.device)
+        for i, (l, (mt, kg)) in enumerate(zip(lins, tiles)):
+            _lib.check(lib.cmf_pack_mlp_layer(_p(l.weight.detach().contiguous()), _p(l.bias.detach().contiguous()), l.out_features,
+                                              l.in_features, int(i == 0), mt, kg, C.c_void_p(flat.data_ptr() + 4 * offs[i]), None,
+                                              _stream()), "cmf_pack_mlp_layer")
+        return flat, offs, [lins[0].in_features] + [l.out_features for l in lins]
+
+    return DERIVED.get((id(lins[0].weight), "mlp-images"), params, build)
+
+
+def mlp_coupler(net, z, T, view, maps, decode, lj=None, ncols=None):
+    """One fused coupling layer with an MLP coupler: in place on ``z`` (B, D) and, with a tangent stack ``T`` (fmajor, 16
+    columns of which ``ncols`` <= 15 are used), on the modified rows of ``T``."""
+    flat, offs, widths = _mlp_images(net)
+    B = z.shape[0]
+    z2 = z.view(B, -1)
+    a = _lib.MlpCouplerArgs()
+    a.z, a.z_b = _p(z2), z2.shape[1]
+    if T is not None:
+        assert decode and T.layout == "fmajor" and T.nc == 16 and (ncols is None or ncols <= 15)
+        a.t, a.t_f = _p(T.data), T.t_r
+    a.w = _p(flat)
+    a.zi, a.si, a.ti, a.n_mod = _p(maps["zi"]), _p(maps["si"]), _p(maps["ti"]), maps["n"]
+    a.B, a.cin, a.chan_off, a.chan_step = B, view.cin, view.chan_off, view.chan_step
+    a.n_layers = len(offs)
+    for i, w_ in enumerate(widths):
+        a.width[i] = w_
+    for i, o in enumerate(offs):
+        a.w_off[i] = o
+    a.decode = int(decode)
+    a.lj = _p(lj)
+    launch = lambda: _lib.check(_lib.load().cmf_mlp_coupler(C.byref(a), _stream()), "cmf_mlp_coupler")
+    if TIMER is None:
+        return launch()
+    # algorithmic work: 2 in out FLOP per layer and column (1 primal + ncols tangents, or 1 per sample in primal mode)
+    cols = (1 + (ncols if ncols is not None else 15)) if T is not None else 1
+    fl = 2.0 * B * cols * sum(widths[i] * widths[i + 1] for i in range(len(widths) - 1))
+    by = 4.0 * B * cols * (view.cin + 2 * maps["n"])
+    TIMER.wrap("mlp_coupler" + ("_tangent" if T is not None else "_primal"), fl, by, launch)
+
+
 def made_masked_weight(weight, kind, features, multiplier=1):
     """weight * MADE mask (kind 0 input->hidden, 1 hidden->hidden, 2 hidden->output) as a cached (out, in) tensor."""
     def build():

@@ -276,6 +276,40 @@ int cmf_hutch_cotangent(const float* u, const float* eps, const float* w, int d,
                         const float* g_off, const float* g_diag, float* M, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused affine-coupling layer with an MLP coupler (2-D / tabular models, low-dimensional prior flows): the whole coupler
+ * network (get_mlp, networks.py:206-224; tanh rule jvp_layers.py:38-53) for the primal and all Jacobian columns, and the
+ * coupling update (acl.py:101-146), in one persistent launch -- replaces the per-layer cmf_conv_primal / cmf_conv_tangent
+ * launches + cmf_acl_tangent + cmf_acl_primal of one coupling layer.  See csrc/mlp_coupler.hip.
+ *   t != NULL  TANGENT mode (decode only): tangents feature-major with 16 columns, of which at most 15 are Jacobian
+ *              columns (latent_dimension <= 15; column 15 of the tensor must be zero padding): z and the modified rows of
+ *              t are updated in place exactly as cmf_acl_primal(decode) + cmf_acl_tangent would.
+ *   t == NULL  PRIMAL mode: z updated in place (decode != 0: x = z e^{-s} - t; else z = (x + t) e^{s});
+ *              lj[b] += -/+ sum s when lj != NULL.
+ * Limits: hidden widths <= 128, 2 cin <= 256, network outputs <= 64, 2 .. CMF_MLP_MAX_LAYERS linear layers.               */
+#define CMF_MLP_MAX_LAYERS 8
+typedef struct {
+  float* z; long long z_b;            /* primal (B, D): element (b, f) at z + b*z_b + f                                   */
+  float* t; long long t_f;            /* tangents (D, B, 16): element (f, b, col) at t + f*t_f + b*16 + col; or NULL      */
+  const float* w;                     /* layer images (cmf_pack_mlp_layer), layer l at w + w_off[l]; 16-byte aligned      */
+  const int* zi; const int* si; const int* ti; int n_mod;   /* coupling maps as for cmf_acl_primal                          */
+  int B, cin, chan_off, chan_step;    /* the network reads z[b][chan_off + f*chan_step], f < cin                          */
+  int n_layers;                       /* linear layers: tanh after every one but the last                                */
+  int width[CMF_MLP_MAX_LAYERS + 1];  /* width[0] = cin, width[l + 1] = output features of layer l                        */
+  long long w_off[CMF_MLP_MAX_LAYERS];
+  int decode;
+  float* lj;
+} cmf_mlp_coupler_args;
+int cmf_mlp_coupler(const cmf_mlp_coupler_args* a, void* stream);
+/* Layer image for cmf_mlp_coupler from nn.Linear parameters w [out][in], bias [out] (NULL = zeros): MFMA A fragments in the
+ * order the kernel's K-steps consume them (first != 0: the layer that reads the gathered input rows) + bias, zero-padded to
+ * out_tiles x 16 outputs and in_groups x 16 inputs.  The kernel expects: hidden layers out_tiles = HT, later layers
+ * in_groups = HT with HT = cmf_mlp_hidden_tiles(widest hidden layer); first layer in_groups = ceil(cin / 16); last layer
+ * out_tiles = ceil(outputs / 16).  Size query: out == NULL returns the number of floats through *out_floats.            */
+int cmf_pack_mlp_layer(const float* w, const float* bias, int out_features, int in_features, int first, int out_tiles,
+                       int in_groups, float* out, long long* out_floats, void* stream);
+int cmf_mlp_hidden_tiles(int max_hidden_width);
+
+/* ---------------------------------------------------------------------------------------------
  * NSF prior of the low-dimensional flow (config/schemas.py:87-103 -> bijections/nsf.py:86-113,
  * bijections/linear.py:12-34).  The arithmetic is jrmcornish/nsf @ 8e3fe75 (un-vendored: PARITY UNPINNED); implemented
  * from Durkan et al., "Neural Spline Flows" (NeurIPS 2019) -- see csrc/nsf.hip.

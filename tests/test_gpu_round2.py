@@ -463,3 +463,52 @@ def test_full_size_c5_properties():
         head.max_cg_iterations, head.cg_tolerance = 128, 1
         tr2 = core.elbo(xg.clone(), add_reconstruction=True)["elbo"]
         assert bool(torch.isfinite(tr2).all()) and int(head.last_hutchinson["iterations"].max()) == 11
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fused MLP coupling layers (cmf_mlp_coupler) against the per-layer launches
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("name,B", [("c1_sphere", 37), ("c2a_power", 300), ("c2b_hepmass", 4096), ("c2b_hepmass", 5)])
+def test_fused_mlp_coupling_layers_equal_the_per_layer_path(name, B):
+    """One persistent launch per coupling layer (weights streamed through LDS, activations in registers, primal in column
+    slot 15) against the per-layer cmf_conv_primal / cmf_conv_tangent + coupling kernels: elbo, J^T J, latents, samples;
+    ragged batch sizes exercise the tile tails, B = 4096 several tiles per workgroup."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(B, *g["x"].shape[1:], generator=gen)
+    if name == "c1_sphere":
+        x = x / x.norm(dim=1, keepdim=True)
+    x = x.cuda()
+    res = {}
+    for fused in (True, False):
+        E.FUSED_MLP = fused
+        try:
+            with torch.no_grad():
+                out = dens.elbo(x.clone(), add_offdiagonal_metric_reg=True)
+                z_low, low, earliest = head.program.encode(x.clone())
+                res[fused] = dict(elbo=out["elbo"].clone(), jtj=head.last_gram.jtj.clone(), z=z_low, low=low, earliest=earliest,
+                                  sample=dens.fixed_sample(earliest[:4].clone()))
+        finally:
+            E.FUSED_MLP = True
+    for k in res[True]:
+        assert rel(res[True][k], res[False][k]) < 2e-6, k
+
+
+def test_fused_mlp_coupler_is_what_the_golden_vectors_ran_on():
+    """The reference-vector parity tests of the flat models must have gone through the fused kernel: timer names say so."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build("c2b_hepmass")
+    E.TIMER = E.KernelTimer(lambda name: True)
+    try:
+        with torch.no_grad():
+            out = dens.elbo(g["x"].cuda(), add_offdiagonal_metric_reg=True)
+        names = set(E.TIMER.by_name())
+    finally:
+        E.TIMER = None
+    assert rel(out["elbo"], g["elbo_0"]) < 1e-4
+    assert "mlp_coupler_tangent" in names and "mlp_coupler_primal" in names
+    assert not any(n.startswith("conv_tangent") for n in names)
