@@ -5,13 +5,15 @@
 // product is formed as  hi*hi + hi*lo + lo*hi  on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the
 // dropped lo*lo term and the representation residual are ~2^-16 relative, i.e. the result is fp32-grade
 // (measured end to end against an fp64 evaluation of the reference: log-det / likelihood / g_ij within
-// ~1e-6 relative, same as the fp32 path; DESIGN.md section 4.5).  Three bf16 MFMAs replace sixteen fp32
+// ~1e-6 relative, same as the fp32 path; DESIGN.md section 4.1b).  Three bf16 MFMAs replace sixteen fp32
 // MFMA-cycles' worth of work: 16x16x32 does 16 Kflop in 16 cycles, 16x16x4 f32 does 2 Kflop in 32.
 //
 // K mapping: one MFMA contracts 32 K-slots = 4 lane groups x 8 contiguous bf16.  A slot group is one
-// (tap, 8-channel octet) pair: lane group kq of K-step s carries tap 4*s + kq, so a chunk of 8 input
-// channels (the same LDS chunking as the fp32 kernel, 2 workgroups per CU) takes 3 K-steps with taps
-// 9..11 zero-weighted (25 % padding; the kernel is HBM-bound at this speed, not MFMA-bound).
+// (tap, 8-channel octet) pair, packed WITHOUT padding: K-steps 0 / 1 of a chunk carry taps 0-3 / 5-8 of its
+// octet (lane group kq = tap) and the centre taps of four consecutive octets form one K-step executed in
+// every fourth chunk (see the MFMA-wave section below): 9 K-steps per 4 octets.  The kernel is bound by SIMD
+// issue in its MFMA waves and by the clock the chip holds under this load, not by HBM: rocprofv3 counts the
+// matrix pipes busy 64 % of the kernel's cycles at an effective 1.79 GHz (profiles/r02_pmc_conv_tangent_bf16x3.json).
 //
 // LDS images (all reads are 16-byte, linear within a lane group => bank-conflict free):
 //   X hi/lo : [pixel][16 columns][8 channels] bf16   -> B fragment = one ds_read_b128 per lane

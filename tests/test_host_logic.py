@@ -58,8 +58,11 @@ def test_schema_shapes_of_baseline_configs():
     assert s5[4]["log_jacobian_method"] == "hutch_with_cg" and s5[4]["hutchinson_samples"] == 4 and s5[2]["value"] == 0.05
     s1 = schemas.get_schema(schemas.get_config("sphere", latent_dimension=3))
     assert [l["type"] for l in s1] == ["non-square-head", "flatten"] + ["acl"] * 5 + ["non-square-base", "affine"]
+    nsf = [l["type"] for l in schemas.get_schema({**schemas.get_config("power"), "prior": "nsf"})]
+    tail = nsf[nsf.index("non-square-base") + 1:]                       # schemas.py:87-103, :586-626 without 'normalise'
+    assert tail == ["flatten"] + ["rand-channel-perm", "linear", "nsf-ar"] * 5 + ["rand-channel-perm", "linear"]
     with pytest.raises(ValueError):
-        schemas.get_schema({**schemas.get_config("power"), "prior": "nsf"})
+        schemas.get_schema({**schemas.get_config("power"), "prior": "standard-normal"})
     with pytest.raises(KeyError):
         schemas.get_config("power", no_such_key=1)
 
