@@ -96,6 +96,9 @@ SIGNATURES = {
     "cmf_pack_mlp_layer": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp, C.POINTER(_ll), _fp]),
     "cmf_mlp_hidden_tiles": (_i, [_i]),
     "cmf_rq_spline": (_i, [_fp, _ll, _fp, _i, _i, _i, _f, _i, _i, _fp, _ll, _fp, _fp]),
+    "cmf_rq_spline_backward": (_i, [_fp, _ll, _fp, _i, _i, _i, _f, _i, _fp, _ll, _fp, _fp, _ll, _fp, _fp]),
+    "cmf_lu_backward": (_i, [_fp, _fp, _fp, _fp, _i, _f, _fp, _i, _fp, _fp, _fp, _fp, _fp]),
+    "cmf_gaussian_backward": (_i, [_fp, _fp, _i, _i, _fp, _fp]),
     "cmf_lu_weights": (_i, [_fp, _fp, _fp, _i, _f, _fp, _fp, _fp]),
     "cmf_made_mask_weight": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp]),
     "cmf_hutch_metric": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp]),

@@ -415,6 +415,15 @@ class _PriorFlowLayer(Bijection):
     def prior_decode(self, z):
         raise NotImplementedError
 
+    def prior_encode_train(self, u, lj=None):
+        """``prior_encode`` keeping what ``prior_backward`` needs: returns (z, ctx)."""
+        raise NotImplementedError
+
+    def prior_backward(self, dz, ctx, grads, dlj=None):
+        """Cotangent of the layer input from ``dz`` (B, d) and the cotangent ``dlj`` (B,) of the layer's log-jacobian;
+        parameter gradients accumulate into ``grads``."""
+        raise NotImplementedError
+
     def _x_to_z(self, x):
         E.require_gpu(x)
         lj = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
@@ -441,6 +450,12 @@ class RandomChannelwisePermutationBijection(_PriorFlowLayer):
 
     def prior_decode(self, z):
         return E.gather_primal(z, self.inverse_permutation.to(torch.int32), z.shape[1])
+
+    def prior_encode_train(self, u, lj=None):
+        return self.prior_encode(u, lj), None
+
+    def prior_backward(self, dz, ctx, grads, dlj=None):        # z[j] = x[perm[j]]  ->  dx[i] = dz[inverse_perm[i]]
+        return E.gather_primal(dz.contiguous(), self.inverse_permutation.to(torch.int32), dz.shape[1])
 
 
 class _LULinearParameters(nn.Module):
@@ -477,6 +492,26 @@ class LULinearBijection(_PriorFlowLayer):
         # bijections/linear.py:30-34: ``_z_to_x`` calls ``self.linear(z)`` -- the FORWARD map, not the inverse.  Kept as is:
         # samples drawn through an nsf prior see L U z + b here exactly as in the reference (the density path is unaffected).
         return self._affine_map(z, None)
+
+    def prior_encode_train(self, u, lj=None):
+        return self._affine_map(u, lj), u
+
+    def prior_backward(self, dz, ctx, grads, dlj=None):
+        """z = L U x + b, log-jac = sum log diag U: dW = sum dz (x) x through the weight-gradient kernel, then the triangles'
+        and the diagonal's gradients (cmf_lu_backward); dx = (L U)^T dz."""
+        p, n = self.linear, dz.shape[1]
+        W, _ = E.lu_weights(p.lower_entries, p.upper_entries, p.unconstrained_upper_diag, p.eps)
+        gb = E.GroupedBatch(dz.shape[0], dz.device)
+        dW = torch.zeros(n, n, dtype=torch.float32, device=dz.device)
+        dx_g = gb.linear_backward(gb.pack(ctx), gb.pack(dz), W, n, n, dw=dW, db=E._grad_of(grads, p.bias))
+        scratch = torch.empty(1, dtype=torch.float32, device=dz.device)
+        g = lambda t: E._p(E._grad_of(grads, t))
+        E._lib.check(E._lib.load().cmf_lu_backward(
+            E._p(dW), E._p(p.lower_entries.detach().contiguous()), E._p(p.upper_entries.detach().contiguous()),
+            E._p(p.unconstrained_upper_diag.detach().contiguous()), n, float(p.eps),
+            E._p(None if dlj is None else dlj.to(torch.float32).contiguous()), dz.shape[0], E._p(scratch),
+            g(p.lower_entries), g(p.upper_entries), g(p.unconstrained_upper_diag), E._stream()), "cmf_lu_backward")
+        return gb.unpack(dx_g, n).contiguous()
 
 
 class _MaskedLinear(nn.Linear):
@@ -525,17 +560,57 @@ class _MADE(nn.Module):
         self.blocks = nn.ModuleList(blocks)
         self.final_layer = _MaskedLinear(deg, features * output_multiplier, features, True)
 
-    def evaluate(self, x):
+    def _w(self, lin):
+        return E.made_masked_weight(lin.weight, lin.kind, self.features, self.multiplier)
+
+    def evaluate(self, x, save=None):
         """(B, D) -> (B, D * multiplier) spline parameters: masked linear layers through cmf_conv_primal (taps = 1), relu on
-        load, residual add in the epilogue."""
-        F_, K = self.features, self.multiplier
-        w = lambda lin: E.made_masked_weight(lin.weight, lin.kind, F_, K)
+        load, residual add in the epilogue.  ``save`` (a list, training): the input of every block and its inner activation."""
+        w = self._w
         h = E.linear_primal(x, w(self.initial_layer), self.initial_layer.bias.detach())
         for blk in self.blocks:
             l0, l1 = blk.linear_layers
             t = E.linear_primal(h, w(l0), l0.bias.detach(), relu_in=True)
+            if save is not None:
+                save.append((h, t))
             h = E.linear_primal(t, w(l1), l1.bias.detach(), relu_in=True, res=h)
+        if save is not None:
+            save.append(h)
         return E.linear_primal(h, w(self.final_layer), self.final_layer.bias.detach())
+
+    def backward(self, x, saved, dtheta, grads):
+        """Backward of ``evaluate``: parameter gradients (masked like the weights) into ``grads``, returns d x (B, D).
+        Residual block  h' = h + W1 relu(W0 relu(h) + b0) + b1  on the tangent-conv kernels with 16 samples in the column
+        slots: weight gradients with the input's own relu, transposed products with the relu' output factor."""
+        B, dev = x.shape[0], x.device
+        gb = E.GroupedBatch(B, dev)
+        H_, D, K = self.hidden_features, self.features, self.multiplier
+        lib = E._lib.load()
+
+        def wgrad_masked(lin):
+            g = E._grad_of(grads, lin.weight)
+            return g, lambda: E._lib.check(lib.cmf_made_mask_weight(E._p(g), E._p(g), g.shape[0], g.shape[1], lin.kind, D, K,
+                                                                      E._stream()), "cmf_made_mask_weight")
+
+        fl = self.final_layer
+        g, mask = wgrad_masked(fl)
+        dh = gb.linear_backward(gb.pack(saved[-1]), gb.pack(dtheta), self._w(fl), H_, D * K, dw=g, db=E._grad_of(grads, fl.bias))
+        mask()
+        for blk, (h_in, t) in zip(reversed(list(self.blocks)), reversed(saved[:-1])):
+            l0, l1 = blk.linear_layers
+            h_g, t_g = gb.pack(h_in), gb.pack(t)
+            g, mask = wgrad_masked(l1)
+            dt = gb.linear_backward(t_g, dh, self._w(l1), H_, H_, dw=g, db=E._grad_of(grads, l1.bias), relu_in=True, fo_g=t_g)
+            mask()
+            g, mask = wgrad_masked(l0)
+            dh = gb.linear_backward(h_g, dt, self._w(l0), H_, H_, dw=g, db=E._grad_of(grads, l0.bias), relu_in=True, fo_g=h_g,
+                                    res_g=dh)
+            mask()
+        il = self.initial_layer
+        g, mask = wgrad_masked(il)
+        dx_g = gb.linear_backward(gb.pack(x), dh, self._w(il), D, H_, dw=g, db=E._grad_of(grads, il.bias))
+        mask()
+        return gb.unpack(dx_g, D)
 
 
 class _AutoregressiveSplineFlow(nn.Module):
@@ -557,6 +632,24 @@ class AutoregressiveRationalQuadraticSplineBijection(_PriorFlowLayer):
         f = self.flow
         params = f.autoregressive_net.evaluate(u)
         return E.rq_spline(u, params, f.num_bins, f.autoregressive_net.hidden_features, f.tail_bound, inverse=False, lj=lj)
+
+    def prior_encode_train(self, u, lj=None):
+        f = self.flow
+        saved = []
+        params = f.autoregressive_net.evaluate(u, save=saved)
+        z = E.rq_spline(u, params, f.num_bins, f.autoregressive_net.hidden_features, f.tail_bound, inverse=False, lj=lj)
+        return z, (u, params, saved)
+
+    def prior_backward(self, dz, ctx, grads, dlj=None):
+        """z_f = spline(x_f; theta_f(x_{<f})): the direct term dz dz/dx + dlj dlad/dx and the MADE's backward of the parameter
+        cotangents dz dz/dtheta + dlj dlad/dtheta (cmf_rq_spline_backward: forward-mode duals)."""
+        f, (u, params, saved) = self.flow, ctx
+        net = f.autoregressive_net
+        dx, dparams = E.rq_spline_backward(u, params, f.num_bins, net.hidden_features, f.tail_bound, dz,
+                                           None if dlj is None else dlj.to(torch.float32).contiguous())
+        dx_net = net.backward(u, saved, dparams, grads)
+        E.accumulate_any(dx, dx_net.contiguous())
+        return dx
 
     def prior_decode(self, z):
         """AutoregressiveTransform.inverse: D passes of (MADE, elementwise inverse spline); pass i fixes feature i."""

@@ -129,7 +129,188 @@ __global__ void made_mask_kernel(const float* __restrict__ w, float* __restrict_
   out[idx] = keep ? w[idx] : 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Training: first derivatives of the spline by forward-mode dual numbers.  z(x, theta) and lad(x, theta) = log dz/dx are
+// evaluated 3 bins times with one seeded input each (x and the 3 bins - 1 parameters of the feature): ~25 evaluations of a
+// ~150-flop function per (sample, feature) on (B, d <= 128) tensors -- negligible next to the decode, and no hand-derived
+// softmax / cumulative-sum / quotient-rule chains to get wrong.  The bin index is piecewise constant (as in autograd).
+// ---------------------------------------------------------------------------------------------------------------------
+struct Dual {
+  float v, d;
+};
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+  const float q = a.v / b.v;
+  return {q, (a.d - q * b.d) / b.v};
+}
+__device__ __forceinline__ Dual operator*(float a, Dual b) { return {a * b.v, a * b.d}; }
+__device__ __forceinline__ Dual operator+(float a, Dual b) { return {a + b.v, b.d}; }
+__device__ __forceinline__ Dual dexp(Dual a) {
+  const float e = expf(a.v);
+  return {e, e * a.d};
+}
+__device__ __forceinline__ Dual dlog(Dual a) { return {logf(a.v), a.d / a.v}; }
+__device__ __forceinline__ Dual dsoftplus(Dual a) {
+  const float sg = 1.f / (1.f + expf(-a.v));        // d softplus = sigmoid
+  return {softplusf(a.v), sg * a.d};
+}
+
+// forward spline on duals; seed: -1 = x, k >= 0 = parameter k.  Returns z and lad (inside the tails only; caller checks).
+__device__ void spline_dual(float xv, const float* __restrict__ p, int bins, float isq, float tail, int seed, Dual& z, Dual& lad) {
+  Dual cw[MAX_BINS + 1], ch[MAX_BINS + 1], der[MAX_BINS + 1];
+  float mw = -3.0e38f, mh = -3.0e38f;
+  for (int i = 0; i < bins; ++i) {
+    mw = fmaxf(mw, p[i] * isq);
+    mh = fmaxf(mh, p[bins + i] * isq);
+  }
+  auto par = [&](int k, float scale) { return Dual{p[k] * scale, seed == k ? scale : 0.f}; };
+  Dual sw{0.f, 0.f}, sh{0.f, 0.f};
+  for (int i = 0; i < bins; ++i) {
+    cw[i + 1] = dexp(par(i, isq) - Dual{mw, 0.f});
+    ch[i + 1] = dexp(par(bins + i, isq) - Dual{mh, 0.f});
+    sw = sw + cw[i + 1];
+    sh = sh + ch[i + 1];
+  }
+  const float scale = 1.f - MIN_BIN * bins;
+  Dual aw{0.f, 0.f}, ah{0.f, 0.f};
+  cw[0] = ch[0] = Dual{-tail, 0.f};
+  for (int i = 1; i <= bins; ++i) {
+    aw = aw + (MIN_BIN + scale * (cw[i] / sw));
+    ah = ah + (MIN_BIN + scale * (ch[i] / sh));
+    cw[i] = (2.f * tail) * aw - Dual{tail, 0.f};
+    ch[i] = (2.f * tail) * ah - Dual{tail, 0.f};
+  }
+  cw[bins] = ch[bins] = Dual{tail, 0.f};
+  der[0] = der[bins] = Dual{1.f, 0.f};
+  for (int i = 1; i < bins; ++i) der[i] = MIN_DER + dsoftplus(par(2 * bins + i - 1, 1.f));
+  int k = 0;
+  for (int i = 1; i < bins; ++i) k += xv >= cw[i].v ? 1 : 0;
+  const Dual x{xv, seed < 0 ? 1.f : 0.f};
+  const Dual w = cw[k + 1] - cw[k], h = ch[k + 1] - ch[k], delta = h / w, d0 = der[k], d1 = der[k + 1];
+  const Dual s2 = d0 + d1 - 2.f * delta;
+  const Dual th = (x - cw[k]) / w;
+  const Dual one{1.f, 0.f};
+  const Dual t1 = th * (one - th);
+  const Dual den = delta + s2 * t1;
+  z = ch[k] + h * (delta * th * th + d0 * t1) / den;
+  const Dual dnum = delta * delta * (d1 * th * th + 2.f * (delta * t1) + d0 * (one - th) * (one - th));
+  lad = dlog(dnum) - 2.f * dlog(den);
+}
+
+// dx[b][f] = dz dz/dx + dlj[b] dlad/dx;  dparams[b][f][k] = dz dz/dtheta_k + dlj[b] dlad/dtheta_k.  One thread per (b, f, seed).
+__global__ void rq_spline_backward_kernel(const float* __restrict__ x, long long x_b, const float* __restrict__ params, int D,
+                                          int bins, float isq, float tail, int B, const float* __restrict__ dz, long long dz_b,
+                                          const float* __restrict__ dlj, float* __restrict__ dx, long long dx_b,
+                                          float* __restrict__ dparams) {
+  const int K = 3 * bins - 1, S = K + 1;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * D * S) return;
+  const int seed = (int)(i % S) - 1;                 // -1 = x
+  const long long bf = i / S;
+  const int f = (int)(bf % D);
+  const long long b = bf / D;
+  const float xv = x[b * x_b + f];
+  const float gz = dz[b * dz_b + f], gl = dlj ? dlj[b] : 0.f;
+  float out;
+  if (xv >= -tail && xv <= tail) {
+    Dual z, lad;
+    spline_dual(xv, params + (b * D + f) * K, bins, isq, tail, seed, z, lad);
+    out = gz * z.d + gl * lad.d;
+  } else {
+    out = seed < 0 ? gz : 0.f;                       // identity tails: dz/dx = 1, lad = 0, no parameter dependence
+  }
+  if (seed < 0) dx[b * dx_b + f] = out;
+  else dparams[(b * D + f) * K + seed] = out;
+}
+
+// LULinear backward from dW = sum_b dy (x) x (n x n):  dL = dW U^T (strict lower),  dU = L^T dW (upper incl. diagonal);
+// diag(U) = softplus(u) + eps  ->  g_u[i] += (dU_ii + dlj_sum / diag_i) sigmoid(u_i)   (log-jac = sum log diag(U)).
+__global__ __launch_bounds__(256) void lu_backward_kernel(const float* __restrict__ dW, const float* __restrict__ lower,
+                                                           const float* __restrict__ upper, const float* __restrict__ udiag, int n,
+                                                           float eps, const float* __restrict__ dlj_sum, float* __restrict__ g_lower,
+                                                           float* __restrict__ g_upper, float* __restrict__ g_udiag) {
+  auto Lij = [&](int i, int j) { return j > i ? 0.f : (j == i ? 1.f : lower[i * (i - 1) / 2 + j]); };
+  auto Uij = [&](int i, int j) {
+    return j < i ? 0.f : (j == i ? softplusf(udiag[i]) + eps : upper[i * n - i * (i + 1) / 2 + (j - i - 1)]);
+  };
+  const float gl = dlj_sum ? dlj_sum[0] : 0.f;
+  for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx % n;
+    if (j < i) {                                     // dL_ij = sum_k dW_ik U_jk
+      float acc = 0.f;
+      for (int k = j; k < n; ++k) acc += dW[i * n + k] * Uij(j, k);
+      g_lower[i * (i - 1) / 2 + j] += acc;
+    } else {                                         // dU_ij = sum_k L_ki dW_kj
+      float acc = 0.f;
+      for (int k = i; k < n; ++k) acc += Lij(k, i) * dW[k * n + j];
+      if (j == i) {
+        const float sg = 1.f / (1.f + expf(-udiag[i]));
+        g_udiag[i] += (acc + gl / (softplusf(udiag[i]) + eps)) * sg;
+      } else {
+        g_upper[i * n - i * (i + 1) / 2 + (j - i - 1)] += acc;
+      }
+    }
+  }
+}
+
+// du[b][f] = -dlow[b] u[b][f]: cotangent of log N(u; 0, I) scaled by the cotangent of the low-dimensional elbo
+__global__ void gaussian_backward_kernel(const float* __restrict__ u, const float* __restrict__ dlow, int n, long long total,
+                                         float* __restrict__ du) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) du[i] = -dlow[i / n] * u[i];
+}
+
+// single-block sum of B floats (the LULinear log-jac cotangent: the same constant is added to every sample's log-jac)
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+
 }  // namespace
+
+extern "C" int cmf_rq_spline_backward(const float* x, long long x_b, const float* params, int D, int bins, int hidden,
+                                      float tail_bound, int B, const float* dz, long long dz_b, const float* dlj, float* dx,
+                                      long long dx_b, float* dparams, void* stream) {
+  if (!x || !params || !dz || !dx || !dparams || D <= 0 || B <= 0 || bins < 2 || bins > MAX_BINS || hidden <= 0 || !(tail_bound > 0.f))
+    return CMF_EINVAL;
+  const long long total = (long long)B * D * (3 * bins);
+  if (total > 0x7fffffffLL * 256) return CMF_ERANGE;
+  hipLaunchKernelGGL(rq_spline_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_b,
+                     params, D, bins, 1.f / sqrtf((float)hidden), tail_bound, B, dz, dz_b, dlj, dx, dx_b, dparams);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cmf_lu_backward(const float* dW, const float* lower, const float* upper, const float* unconstrained_diag, int n,
+                               float eps, const float* dlj, int B, float* scratch1, float* g_lower, float* g_upper, float* g_udiag,
+                               void* stream) {
+  if (!dW || !unconstrained_diag || !g_udiag || n <= 0 || n > 1024 || (n > 1 && (!lower || !upper || !g_lower || !g_upper)))
+    return CMF_EINVAL;
+  if (dlj && (!scratch1 || B <= 0)) return CMF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dlj) {
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, dlj, B, scratch1);
+    CMF_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(lu_backward_kernel, dim3(1), dim3(256), 0, s, dW, lower, upper, unconstrained_diag, n, eps,
+                     dlj ? scratch1 : nullptr, g_lower, g_upper, g_udiag);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cmf_gaussian_backward(const float* u, const float* dlow, int n, int B, float* du, void* stream) {
+  if (!u || !dlow || !du || n <= 0 || B <= 0) return CMF_EINVAL;
+  const long long total = (long long)n * B;
+  hipLaunchKernelGGL(gaussian_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, dlow, n,
+                     total, du);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int cmf_rq_spline(const float* x, long long x_b, const float* params, int D, int bins, int hidden, float tail_bound,
                              int inverse, int B, float* out, long long out_b, float* lj, void* stream) {

@@ -535,10 +535,10 @@ class FlowProgram:
         lj = torch.zeros(B, dtype=torch.float32, device=x.device)
         pctx = []
         for m in self.prior:
-            if isinstance(m, _PriorFlowLayer):
-                raise NotImplementedError("training gradients through the nsf prior layers (rand-channel-perm / LULinear / "
-                                          "autoregressive spline) are not built: evaluation and sampling only")
-            if isinstance(m, (AffineCouplingBijection, AffineBijection)):
+            if isinstance(m, _PriorFlowLayer):                     # nsf prior layers: out of place
+                u, c = m.prior_encode_train(u, lj)
+                pctx.append((m, c))
+            elif isinstance(m, (AffineCouplingBijection, AffineBijection)):
                 pctx.append((m, m.encode_train_(u, lj)))
         if self.gaussian._nonstandard():
             raise NotImplementedError("training gradients with a non-standard base Gaussian are not built")
@@ -548,9 +548,15 @@ class FlowProgram:
     def prior_backward(self, pctx, u, dlow, grads):
         """Backward of the low-dimensional prior chain: ``dlow`` (B,) = cotangent of low_dim_elbo = log N(u) + sum log-jac;
         returns the cotangent of z_low (B, d) and accumulates the prior flows' parameter gradients."""
-        du = (-u * dlow.view(-1, 1)).contiguous()
+        du = torch.empty_like(u)
+        dlow = dlow.to(torch.float32).contiguous()
+        E._lib.check(E._lib.load().cmf_gaussian_backward(E._p(u.contiguous()), E._p(dlow), u.shape[1], u.shape[0], E._p(du),
+                                                         E._stream()), "cmf_gaussian_backward")
         for m, c in reversed(pctx):
-            m.encode_backward_(du, c, grads, dlj=dlow)
+            if isinstance(m, _PriorFlowLayer):
+                du = m.prior_backward(du, c, grads, dlj=dlow)
+            else:
+                m.encode_backward_(du, c, grads, dlj=dlow)
         return du
 
     def encode_backward(self, ctx, dz_low, grads):

@@ -399,6 +399,18 @@ def accumulate(dst, src):
     _lib.check(_lib.load().cmf_accumulate(_p(dst), _p(src), min(dst.numel(), src.numel()), _stream()), "cmf_accumulate")
 
 
+def accumulate_any(dst, src):
+    """dst += src for flat fp32 tensors of any length: cmf_tanh_backward with a = 0 computes (dst + src) (1 - 0) in place."""
+    n = dst.numel()
+    assert src.numel() == n
+    zero = torch.zeros(1, dtype=torch.float32, device=dst.device)
+    if n % 4 == 0 and dst.data_ptr() % 16 == 0 and src.data_ptr() % 16 == 0:
+        return accumulate(dst, src)
+    # odd sizes: elementwise kernel with a broadcast-free formulation: out = (dh + extra) * (1 - a^2) needs a of length n
+    a = torch.zeros(n, dtype=torch.float32, device=dst.device)
+    _lib.check(_lib.load().cmf_tanh_backward(_p(dst), _p(a), _p(src), n, _p(dst), _stream()), "cmf_tanh_backward")
+
+
 def stanh_backward(dy, dg, y, g, sw, sb, dsw=None, dsb=None):
     """ScaledTanh output stage backward: returns du for y = sw tanh(u) + sb, g = sw (1 - tanh^2) given the cotangents of y and g
     (``dg`` may be None); accumulates the parameter gradients into ``dsw`` / ``dsb`` (C floats each) when given."""
@@ -647,6 +659,53 @@ def linear_primal(x, weight, bias, relu_in=False, res=None):
     y = torch.empty(B, cout, dtype=torch.float32, device=x.device)
     conv_primal(x, 0, 0, 1, cin, weight, 1, bias, y, 0, 1, cout, 1, cin, cout, 1, B, imode=F_RELU if relu_in else F_NONE, res=res)
     return y
+
+
+class GroupedBatch:
+    """(B, F) tensors with 16 samples in the 16 column slots of the tangent-conv kernels -- (G, F, 16), viewed as ONE image row of
+    G pixels -- for the backward of small linear layers (MLP couplers, the nsf prior's MADE and LULinear) on those kernels."""
+
+    def __init__(self, B, device):
+        self.B, self.Bp, self.dev = B, (B + 15) // 16 * 16, device
+        self.G = self.Bp // 16
+
+    def pack(self, t):
+        t = t.reshape(self.B, -1)
+        if self.Bp != self.B:
+            t = torch.cat([t, torch.zeros(self.Bp - self.B, t.shape[1], dtype=t.dtype, device=self.dev)])
+        return primal_regroup(t.contiguous(), True)
+
+    def unpack(self, t_g, F):
+        return primal_regroup(t_g.view(self.G, -1), False).view(self.Bp, F)[: self.B]
+
+    @staticmethod
+    def strides(c):
+        return (0, 16, c * 16)                               # (np, chan, px)
+
+    def linear_backward(self, x_g, dy_g, weight, cin, cout, dw=None, db=None, relu_in=False, fo_g=None, res_g=None):
+        """y = W [relu](x) + b on grouped tensors: dw += sum dy (x) [relu](x), db += sum dy, returns W^T dy (optionally
+        times [fo > 0], plus res)."""
+        if dw is not None:
+            conv_tangent_wgrad(x_g, 0, *self.strides(cin), dy_g, 0, *self.strides(cout), dw, 1, 1, cin, cout, 1, self.G, 16,
+                               fmode=F_SELF_RELU if relu_in else F_NONE)
+        if db is not None:
+            channel_sum(dy_g, *self.strides(cout), 1, cout, self.G, 16, db)
+        dx_g = torch.empty(self.G * cin * 16, dtype=torch.float32, device=self.dev)
+        fo = {} if fo_g is None else dict(fo=fo_g, fo_np=0, fo_co=16, fo_px=cin * 16, fomode=F_SELF_RELU)
+        conv_tangent(dy_g, 0, *self.strides(cout), weight, 1, dx_g, *self.strides(cin), 1, cout, cin, 1, self.G, 16,
+                     transpose=True, precision="f32", res_t=res_g, **fo)
+        return dx_g
+
+
+def rq_spline_backward(x, params, bins, hidden, tail_bound, dz, dlj=None):
+    """(dx (B, D), dparams (B, D * (3 bins - 1))) of the forward spline for the cotangents dz (B, D) and dlj (B,)."""
+    B, D = x.shape
+    dx = torch.empty_like(x)
+    dparams = torch.empty_like(params)
+    _lib.check(_lib.load().cmf_rq_spline_backward(_p(x), D, _p(params), D, int(bins), int(hidden), float(tail_bound), B,
+                                                  _p(dz.contiguous()), D, _p(dlj), _p(dx), D, _p(dparams), _stream()),
+               "cmf_rq_spline_backward")
+    return dx, dparams
 
 
 def rq_spline(x, params, bins, hidden, tail_bound, inverse=False, lj=None):

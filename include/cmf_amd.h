@@ -319,6 +319,17 @@ int cmf_mlp_hidden_tiles(int max_hidden_width);
  *   lj[b] += sum_f log |d out / d x| (NULL to skip).  out may alias x.                                                */
 int cmf_rq_spline(const float* x, long long x_b, const float* params, int D, int bins, int hidden, float tail_bound,
                   int inverse, int B, float* out, long long out_b, float* lj, void* stream);
+/* Training: cotangents of x and of the spline parameters from dz (B, D) and dlj (B,) (NULL = 0):
+ *   dx(b,f) = dz dz/dx + dlj[b] d log|dz/dx| / dx;   dparams [B][D][3 bins - 1] likewise per parameter.  Forward direction only. */
+int cmf_rq_spline_backward(const float* x, long long x_b, const float* params, int D, int bins, int hidden, float tail_bound,
+                           int B, const float* dz, long long dz_b, const float* dlj, float* dx, long long dx_b,
+                           float* dparams, void* stream);
+/* LULinear backward from dW [n][n] = sum_b dy (x) x: gradients of the strict triangles and of the unconstrained diagonal
+ * (accumulated), including the log-jac term sum_b dlj[b] * d(sum log diag U) (dlj: (B,) or NULL; scratch1: 1 float).      */
+int cmf_lu_backward(const float* dW, const float* lower, const float* upper, const float* unconstrained_diag, int n, float eps,
+                    const float* dlj, int B, float* scratch1, float* g_lower, float* g_upper, float* g_udiag, void* stream);
+/* du(b, f) = -dlow[b] u(b, f): backward of the standard-normal log-density (gaussian.py:9-22)                           */
+int cmf_gaussian_backward(const float* u, const float* dlow, int n, int B, float* du, void* stream);
 /* LULinear: W [n][n] = L U (L unit lower from `lower`, U upper from `upper` with diagonal softplus(unconstrained_diag) +
  * eps; entry order of np.tril_indices(n, -1) / np.triu_indices(n, 1)); logdet[0] = sum log diag(U).                   */
 int cmf_lu_weights(const float* lower, const float* upper, const float* unconstrained_diag, int n, float eps, float* W,
