@@ -931,16 +931,19 @@ class NonSquareHeadDensity(Density):
         ``train_backward`` needs (every layer's input, activations, input tangents: ~17 hidden tangent tensors per ResNet
         coupler stay alive -- 131 GB for MNIST d = 64 at the reference's 64 samples per GPU).  ``x`` = the head's input."""
         E.require_gpu(x)
-        if self._jacobian_free:
-            raise NotImplementedError("training gradients of the M-flow baseline head are not built")
         assert not (add_diagonal_metric_reg and add_offdiagonal_metric_reg)
         prog, B, dev = self.program, x.shape[0], x.device
         want_lik = not np.isclose(likelihood_wt, 0.)
-        hutch = want_lik and self.training and self.log_jacobian_method == "hutch_with_cg"     # non_square.py:131-138
+        # M-flow baseline (non_square.py:341-346): the likelihood term is the low-dimensional elbo alone -- no Jacobian, no
+        # log-det, and the metric terms have no J^T J to act on (the reference fails on its None)
+        want_jac = want_lik and not self._jacobian_free
+        if self._jacobian_free and want_lik and (add_diagonal_metric_reg or add_offdiagonal_metric_reg):
+            raise ValueError("the M-flow head has no J^T J: metric regularisation is not defined for it (non_square.py:87-100)")
+        hutch = want_jac and self.training and self.log_jacobian_method == "hutch_with_cg"     # non_square.py:131-138
         if hutch:
             self._check_hutchinson_metric(add_diagonal_metric_reg or add_offdiagonal_metric_reg)
         keep = True
-        if want_lik:
+        if want_jac:
             nc = E.ceil16(prog.d)
             free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
             keep = (B * prog.train_bytes_per_sample(nc) <= 0.8 * free) if self.recompute is None else not self.recompute
@@ -952,19 +955,20 @@ class NonSquareHeadDensity(Density):
         with torch.no_grad():
             x = x.contiguous()
             z_low, low_elbo, u, ctx, pctx = prog.encode_train(x)
-            head = self.head_terms_forward(z_low, tangents=want_lik, hutch_eps=self._hutchinson_probes(B, dev) if hutch else None,
+            head = self.head_terms_forward(z_low, tangents=want_jac, hutch_eps=self._hutchinson_probes(B, dev) if hutch else None,
                                            keep=keep)
             gr = head["gram"]
             rec = E.recon_sqerr(head["x_hat"], x) if add_reconstruction else None
             l1 = logdet = None
-            if want_lik:
+            if want_jac:
                 src = head["hutch"] if hutch else {"l1_off": gr.l1_off, "l1_diag": gr.l1_diag}
                 l1 = src["l1_diag"] if add_diagonal_metric_reg else (src["l1_off"] if add_offdiagonal_metric_reg else None)
                 logdet = head["hutch"]["value"] if hutch else gr.logdet
             elbo = E.elbo_combine(low_elbo if want_lik else None, logdet, rec, l1, pre_logjac,
                                   likelihood_wt, self.regularization_param, metric_wt, B, dev)
         prior_dict = {"elbo": low_elbo.view(B, 1), "low-dim-x": z_low}
-        state = dict(x=x, z_low=z_low, u=u, ctx=ctx, pctx=pctx, head=head, want_lik=want_lik, rec=add_reconstruction, prior_dict=prior_dict,
+        state = dict(x=x, z_low=z_low, u=u, ctx=ctx, pctx=pctx, head=head, want_lik=want_lik, want_jac=want_jac, rec=add_reconstruction,
+                     prior_dict=prior_dict,
                      diag=add_diagonal_metric_reg, off=add_offdiagonal_metric_reg, wl=float(likelihood_wt), wm=float(metric_wt))
         return elbo, state
 
@@ -977,11 +981,11 @@ class NonSquareHeadDensity(Density):
         lam = float(self.regularization_param)
         with torch.no_grad():
             # elbo_b = wl (low_b - logdet_b / 2) - lam rec_b - wm l1_b
-            lik = state["want_lik"]
+            lik, jac = state["want_lik"], state["want_jac"]
             out = self.head_terms_backward(state["z_low"], state["x"],
-                                           g_logdet=w * (-0.5 * state["wl"]) if lik else None,
-                                           g_l1off=w * (-state["wm"]) if lik and state["off"] else None,
-                                           g_l1diag=w * (-state["wm"]) if lik and state["diag"] else None,
+                                           g_logdet=w * (-0.5 * state["wl"]) if jac else None,
+                                           g_l1off=w * (-state["wm"]) if jac and state["off"] else None,
+                                           g_l1diag=w * (-state["wm"]) if jac and state["diag"] else None,
                                            g_rec=w * (-lam) if state["rec"] else None, grads=grads, state=state["head"])
             dz_low = out["dz_low"]
             if lik:

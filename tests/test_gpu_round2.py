@@ -554,3 +554,64 @@ def test_fused_mlp_coupler_is_what_the_golden_vectors_ran_on():
     assert rel(out["elbo"], g["elbo_0"]) < 1e-4
     assert "mlp_coupler_tangent" in names and "mlp_coupler_primal" in names
     assert not any(n.startswith("conv_tangent") for n in names)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# M-flow baseline head (m_flow: True): Jacobian-free likelihood term, detached latent before the prior
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("lw,rec", [(1.0, False), (0.0, True), (1.0, True)])
+def test_m_flow_head_trains_like_the_reference_objectives(lw, rec):
+    """ManifoldFlowHeadDensity (non_square.py:341-364): elbo = w_L low_dim_elbo - lambda rec with the latent DETACHED before the
+    prior (non_square.py:388-389), alternating objectives (non_square_helpers.py:52-66): the likelihood objective trains the prior
+    flows only, the reconstruction objective the coupling stack only.  Gradients against autograd through the float64 oracle
+    pieces."""
+    import cmf_amd
+    from cmf_amd.recipe import fill_state_dict
+    from oracle import cmf_oracle as O
+    cfg = cmf_amd.get_config("power", m_flow=True)
+    schema, shape = cmf_amd.get_schema(cfg), cmf_amd.DATA_SHAPES["power"]
+    dens = cmf_amd.get_density(schema, torch.zeros(1, *shape))
+    sd = fill_state_dict(dens.state_dict(), seed=0)
+    dens.load_state_dict(sd)
+    dens = dens.cuda()
+    head = [m for m in dens.modules() if type(m).__name__ == "ManifoldFlowHeadDensity"][0]
+    named = dict(dens.named_parameters())
+    ops = O.compile_schema(schema, shape)
+    pre, hd, flow_ops, base, prior_ops = O.split_ops(ops)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(7, *shape, generator=gen)
+    keys = [k for k, v in sd.items() if v.is_floating_point() and k in named]
+    sd64 = {k: (v.double().clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    xd = x.double()
+    z_low, _, _ = O.encode(sd64, flow_ops, base, [], xd)                      # the coupling stack above the tail
+    u, lj = z_low.detach(), torch.zeros(7, 1, dtype=torch.float64)            # prior chain on the DETACHED latent
+    for op in prior_ops:
+        if op["kind"] == "acl":
+            u, l = O.acl_x_to_z(sd64, op, u)
+            lj = lj + l
+        elif op["kind"] == "gaussian":
+            lj = lj + O.gaussian_log_prob(u)
+    xh = O.flow_forward(sd64, flow_ops, base, z_low)
+    recon = ((xh - xd).flatten(1) ** 2).sum(-1, keepdim=True)
+    want_elbo = lw * lj - (hd["regularization_param"] * recon if rec else 0)
+    want = torch.autograd.grad(-want_elbo.mean(), [sd64[k] for k in keys], allow_unused=True)
+    loss, elbo, grads = head.loss_and_gradients(x.cuda(), likelihood_wt=lw, add_reconstruction=rec)
+    assert rel(elbo, want_elbo) < 1e-4
+    n_prior = n_flow = 0
+    for k, w in zip(keys, want):
+        p_ = named[k]
+        zero = w is None or float(w.abs().max()) == 0.0
+        if zero:
+            assert p_ not in grads or float(grads[p_].abs().max()) < 1e-10, k
+            continue
+        assert rel(grads[p_], w.reshape(p_.shape)) < 1e-4, k
+        below_tail = k.count("prior.") > 12                                   # flatten + 10 couplings + the tail hang off the head
+        n_prior += below_tail
+        n_flow += not below_tail
+    assert (n_prior > 0) == (lw > 0) and (n_flow > 0) == rec
+    with pytest.raises(ValueError, match="M-flow"):
+        head.loss_and_gradients(x.cuda(), add_offdiagonal_metric_reg=True)
+    groups = cmf_amd.get_non_square_parameters(dens, True)
+    assert len(groups) == 2 and sum(1 for _ in groups[0]) > 0 and sum(1 for _ in groups[1]) > 0
