@@ -48,7 +48,7 @@ class MlpCouplerArgs(C.Structure):
     _fields_ = [("z", _fp), ("z_b", _ll), ("t", _fp), ("t_f", _ll), ("w", _fp),
                 ("zi", _fp), ("si", _fp), ("ti", _fp), ("n_mod", _i),
                 ("B", _i), ("cin", _i), ("chan_off", _i), ("chan_step", _i), ("n_layers", _i),
-                ("width", _i * (MLP_MAX_LAYERS + 1)), ("w_off", _ll * MLP_MAX_LAYERS), ("decode", _i), ("lj", _fp)]
+                ("width", _i * (MLP_MAX_LAYERS + 1)), ("w_off", _ll * MLP_MAX_LAYERS), ("decode", _i), ("lj", _fp), ("ncols", _i)]
 
 
 #: every symbol include/cmf_amd.h declares -> (restype, argtypes)

@@ -618,6 +618,7 @@ def mlp_coupler(net, z, T, view, maps, decode, lj=None, ncols=None):
         a.w_off[i] = o
     a.decode = int(decode)
     a.lj = _p(lj)
+    a.ncols = int(ncols) if (T is not None and ncols is not None) else 15
     launch = lambda: _lib.check(_lib.load().cmf_mlp_coupler(C.byref(a), _stream()), "cmf_mlp_coupler")
     if TIMER is None:
         return launch()

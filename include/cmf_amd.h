@@ -280,9 +280,9 @@ int cmf_hutch_cotangent(const float* u, const float* eps, const float* w, int d,
  * network (get_mlp, networks.py:206-224; tanh rule jvp_layers.py:38-53) for the primal and all Jacobian columns, and the
  * coupling update (acl.py:101-146), in one persistent launch -- replaces the per-layer cmf_conv_primal / cmf_conv_tangent
  * launches + cmf_acl_tangent + cmf_acl_primal of one coupling layer.  See csrc/mlp_coupler.hip.
- *   t != NULL  TANGENT mode (decode only): tangents feature-major with 16 columns, of which at most 15 are Jacobian
- *              columns (latent_dimension <= 15; column 15 of the tensor must be zero padding): z and the modified rows of
- *              t are updated in place exactly as cmf_acl_primal(decode) + cmf_acl_tangent would.
+ *   t != NULL  TANGENT mode (decode only): tangents feature-major with 16 column slots of which the first `ncols` <= 15 are
+ *              Jacobian columns (the rest zero padding): z and the modified rows of t are updated in place exactly as
+ *              cmf_acl_primal(decode) + cmf_acl_tangent would.
  *   t == NULL  PRIMAL mode: z updated in place (decode != 0: x = z e^{-s} - t; else z = (x + t) e^{s});
  *              lj[b] += -/+ sum s when lj != NULL.
  * Limits: hidden widths <= 128, 2 cin <= 256, network outputs <= 64, 2 .. CMF_MLP_MAX_LAYERS linear layers.               */
@@ -298,6 +298,7 @@ typedef struct {
   long long w_off[CMF_MLP_MAX_LAYERS];
   int decode;
   float* lj;
+  int ncols;                          /* TANGENT mode: Jacobian columns in use (1 .. 15)                                  */
 } cmf_mlp_coupler_args;
 int cmf_mlp_coupler(const cmf_mlp_coupler_args* a, void* stream);
 /* Layer image for cmf_mlp_coupler from nn.Linear parameters w [out][in], bias [out] (NULL = zeros): MFMA A fragments in the
