@@ -94,6 +94,11 @@ TANGENT_PRECISION = "bf16x3"
 PRIMAL_PRECISION = "f32"
 
 
+#: batches below this many samples run the ResNet couplers' primal pass on cmf_conv_primal (standard layout, one launch grid over
+#: samples x pixel tiles) instead of 16-sample groups through the tangent-conv kernels
+GROUPED_PRIMAL_MIN_BATCH = 16
+
+
 def _use_bf16x3(taps, cin, W, transpose, H=None, cout=64):
     return TANGENT_PRECISION == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
 
