@@ -615,3 +615,84 @@ def test_m_flow_head_trains_like_the_reference_objectives(lw, rec):
         head.loss_and_gradients(x.cuda(), add_offdiagonal_metric_reg=True)
     groups = cmf_amd.get_non_square_parameters(dens, True)
     assert len(groups) == 2 and sum(1 for _ in groups[0]) > 0 and sum(1 for _ in groups[1]) > 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# shape sweeps of the round-2 kernels (tails, padding, tile boundaries)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("N,d,B", [(784, 64, 7), (1, 64, 3), (5, 49, 4), (100, 57, 2), (785, 63, 3), (33, 64, 1), (4099, 50, 2)])
+def test_gram_chol64_shapes(N, d, B):
+    """The d <= 64 kernel (49 <= d <= 64 -> NC = 64): row counts that are not multiples of the 4-row groups / of the prefetch
+    ring, fewer groups than ring slots, latent dimensions below the padded 64, rank-deficient inputs (N < d: pivot failure)."""
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(17 * N + d)
+    J = torch.zeros(B, N, 64)
+    J[:, :, :d] = torch.randn(B, N, d, generator=gen)
+    T = E.Tangent(B, N, 64, "panel", "cuda", data=J.reshape(-1).cuda())
+    gr = E.gram_cholesky(T, d, max_attempts=1)
+    G = torch.einsum("bni,bnj->bij", J[:, :, :d].double(), J[:, :, :d].double())
+    assert rel(gr.jtj, G) < 1e-5
+    diag = torch.diagonal(G, dim1=1, dim2=2).abs().sum(1)
+    assert rel(gr.l1_diag, diag) < 1e-5 and rel(gr.l1_off, G.abs().sum((1, 2)) - diag) < 1e-5
+    if N >= d + 8:
+        assert gr.fail.tolist()[0] == 0 and int(gr.info.abs().max()) == 0
+        assert rel(gr.logdet, torch.linalg.slogdet(G)[1]) < 1e-4
+    elif N < d:                                        # rank N < d: a pivot must fail (exact zeros or rounding-level values)
+        info = gr.info.cpu()
+        assert gr.fail.tolist()[0] == 1 and bool((info > 0).all()) and bool(torch.isnan(gr.logdet).all())
+
+
+@pytest.mark.parametrize("D,hidden,ncols,B", [(6, [128] * 4, 2, 203), (21, [128] * 4, 10, 77), (21, [128] * 4, 15, 40), (9, [100, 70], 4, 31),
+                                              (64, [32] * 4, 1, 65), (3, [10, 10], 3, 19), (43, [128, 16, 128], 7, 129), (8, [33], 5, 16)])
+def test_mlp_coupler_shape_sweep(D, hidden, ncols, B):
+    """cmf_mlp_coupler against the per-layer launches on single coupling layers: odd widths (padded tiles), unequal hidden
+    layers, every packing factor of the TANGENT mode (d = 1 .. 15 -> 8 .. 1 samples per tile), ragged batches, both directions
+    of the PRIMAL mode with the log-jacobian, the M-split primal kernel (hidden > 32) and the per-wave one."""
+    from cmf_amd import engine as E
+    from cmf_amd.bijections import AlternatingChannelwiseAffineCouplingBijection
+    from cmf_amd.networks import ChunkedSharedCoupler, get_mlp
+    torch.manual_seed(100 * D + ncols)
+    for reverse in (False, True):
+        layer = AlternatingChannelwiseAffineCouplingBijection(
+            (D,), lambda npass: ChunkedSharedCoupler(get_mlp(npass, hidden, 2 * (D - npass))), reverse).cuda()
+        for p in layer.parameters():
+            p.data.mul_(0.5)
+        z0 = torch.randn(B, D, device="cuda")
+        V = torch.randn(B, D, ncols, device="cuda")
+        out = {}
+        for fused in (True, False):
+            E.FUSED_MLP = fused
+            try:
+                z = z0.clone()
+                T = E.Tangent.from_dense(V, 16, "fmajor")
+                layer.decode_(z, T, ncols=ncols)
+                ze, lje = z0.clone(), torch.zeros(B, device="cuda")
+                layer.encode_(ze, lje)
+                zd, ljd = z0.clone(), torch.zeros(B, device="cuda")
+                layer.decode_(zd, None, ljd)
+                out[fused] = (z, T.to_dense(16).contiguous(), ze, lje, zd, ljd)
+            finally:
+                E.FUSED_MLP = True
+        for a_, b_ in zip(out[True], out[False]):
+            assert rel(a_, b_) < 5e-6
+        assert float(out[True][1][:, :, ncols:].abs().max()) == 0.0          # padding columns stay zero
+        assert rel(out[True][4], out[True][0]) < 1e-6                           # primal of the tangent mode = primal mode
+
+
+def test_hutch_cg_probe_counts():
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(9)
+    for B, d, S in ((3, 10, 1), (2, 64, 17), (2, 128, 33), (4, 5, 5), (2, 100, 16)):
+        A = torch.randn(B, d + 4, d, generator=gen, dtype=torch.float64)
+        G = torch.bmm(A.transpose(1, 2), A) / d + 0.3 * torch.eye(d, dtype=torch.float64)
+        eps = torch.randn(B, d, S, generator=gen, dtype=torch.float64)
+        val, u, w, iters = E.hutch_cg(G.float().cuda(), eps.float().cuda(), 4 * d, 1e-7)
+        assert rel(w, torch.bmm(G, eps)) < 1e-5 and rel(u, torch.linalg.solve(G, eps)) < 2e-3
+        assert rel(val, (u.cpu().double() * w.cpu().double()).sum(1).mean(1)) < 1e-5
+        if S == d:
+            off, diag = E.hutch_metric(w)
+            W = w.cpu().double()
+            dg = torch.diagonal(W, dim1=1, dim2=2).abs().sum(1)
+            assert rel(diag, dg) < 1e-5 and rel(off, W.abs().sum((1, 2)) - dg) < 1e-5
