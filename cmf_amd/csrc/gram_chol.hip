@@ -412,7 +412,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 template <int PF>
 __global__ __launch_bounds__(256) void gram_chol64_kernel(const float* __restrict__ t, long long t_b, long long t_r,
-                                                           int n_rows, int d, float* __restrict__ jtj,
+                                                           int n_rows, int ncm, int d, float* __restrict__ jtj,
                                                            float* __restrict__ logdet, float* __restrict__ l1_off,
                                                            float* __restrict__ l1_diag, int* __restrict__ info,
                                                            int* __restrict__ fail) {
@@ -439,7 +439,10 @@ __global__ __launch_bounds__(256) void gram_chol64_kernel(const float* __restric
   const int panel_bytes = (int)((long long)n_rows * t_r * 4);
   const int row_bytes = (int)t_r * 4;
   const int group_bytes = 16 * row_bytes;
-  const int voff = (wave * 4 + kq) * row_bytes + cl * NT * 4;
+  // Narrower panels (ncm = 16 / 32 / 48 columns in memory, d <= ncm) run on the same 64-column machinery: the lanes whose four
+  // columns do not exist read through an offset past every descriptor's range (zeros, no traffic), so their rows / columns
+  // of the Gram matrix are exact zeros like the columns >= d; the elimination only visits the first d.
+  const int voff = cl * NT < ncm ? (wave * 4 + kq) * row_bytes + cl * NT * 4 : 0x7ffffff0;
   int goff = 0;
   u32x4 ring[PF];
   auto load = [&](int slot) {
@@ -584,12 +587,12 @@ __global__ __launch_bounds__(256) void gram_chol64_kernel(const float* __restric
 }
 
 template <int PF>
-int launch_gram64(const float* t, long long t_b, long long t_r, int n_rows, int d, int B, float* jtj, float* logdet,
+int launch_gram64(const float* t, long long t_b, long long t_r, int n_rows, int ncm, int d, int B, float* jtj, float* logdet,
                   float* l1_off, float* l1_diag, int* info, int* fail, hipStream_t s) {
   constexpr int lds = 4 * 64 * 68 * 4;
   auto k = gram_chol64_kernel<PF>;
   if (hipError_t e = cmf_set_dynamic_lds((const void*)k, lds); e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k, dim3(B), dim3(256), lds, s, t, t_b, t_r, n_rows, d, jtj, logdet, l1_off, l1_diag, info, fail);
+  hipLaunchKernelGGL(k, dim3(B), dim3(256), lds, s, t, t_b, t_r, n_rows, ncm, d, jtj, logdet, l1_off, l1_diag, info, fail);
   CMF_LAUNCH_CHECK();
   return 0;
 }
@@ -648,7 +651,14 @@ extern "C" int cmf_gram_cholesky(const float* t, long long t_b, long long t_r, i
 #ifndef CMF_DBG_GRAMPF
 #define CMF_DBG_GRAMPF 8                            // measured: 8 groups ahead beat 12 / 16 / 24 by 3 - 12 us at B = 512
 #endif
-  if (nc == 64) return launch_gram64<CMF_DBG_GRAMPF>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
+  // nc <= 64: the d <= 64 kernel (narrower panels through lane masking).  The panel of one sample must fit the 32-bit byte
+  // offsets of its buffer descriptor (feature-major tensors of large batches do not: they keep the LDS-staged kernel)
+#ifndef CMF_DBG_GRAM64_MIN_NC
+#define CMF_DBG_GRAM64_MIN_NC 32                    // measured (B = 512, D = 784): nc 48: 75.6 -> 40.4 us, nc 32: 51.4 -> 38.7 us;
+                                                    // nc 16 (tabular, B = 4096): the small-LDS staged kernel wins, 19.5 vs 51.9 us
+#endif
+  if (nc >= CMF_DBG_GRAM64_MIN_NC && nc <= 64 && (long long)n_rows * t_r * 4 < 0x7fffff00LL)
+    return launch_gram64<CMF_DBG_GRAMPF>(t, t_b, t_r, n_rows, nc, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
   if (nc == 128) return launch_gram_direct<8>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);
 #define CMF_GRAM_CASE(N) \
   case N: return launch_gram<N>(t, t_b, t_r, n_rows, d, B, jtj, logdet, l1_off, l1_diag, info, fail, s);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the fused Gram + Cholesky kernel: python tools/bench_gram.py [B N d]
+"""Time the fused Gram + Cholesky kernel: python tools/bench_gram.py [B N d [B N d ...]]
 
 CMF_DBG_LIB=dbg_<FLAGS>.so selects a diagnostic build (tools/build_dbg.sh): GSTAMP adds per-workgroup phase time stamps
 (Gram loop / reduction + output / elimination) which are summarised here, GRAMOLD runs the round-1 kernel, GRAMPF=<n> sets the
@@ -43,6 +43,9 @@ def run(B, N, d, iters=20):
 
 args = [int(a) for a in sys.argv[1:]]
 print("lib:", os.environ.get("CMF_DBG_LIB", "libcmf_amd.so"))
-if args: run(*args)
+if args:
+    for i in range(0, len(args) - 2, 3): run(*args[i:i + 3])          # any number of "B N d" triples
 else:
     run(512, 784, 64); run(512, 16, 64); run(512, 3072, 128); run(512, 16, 128); run(4096, 784, 64); run(256, 784, 64); run(512, 784, 48)
+if not args:
+    run(512, 784, 20); run(4096, 21, 10)
