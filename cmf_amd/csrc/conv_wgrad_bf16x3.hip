@@ -6,7 +6,7 @@
 // Why a second kernel: in the fp32 version each of the four output-channel waves loads and masks the same input columns from
 // global memory and keeps them in a register ring.  Here a 512-thread workgroup shares the work through LDS:
 //   * K of one MFMA = 32 = two 16-column slices of one pixel; lane (r, kg) of a fragment holds 8 consecutive columns
-//     (32 bytes of fp32 in global memory) of channel r, slice 2 sp + kg / 2 -- the same mapping for both operands;
+//     of channel r, slice 2 sp + kg / 2 -- the same mapping for both operands;
 //   * per image column (one "slot", conv_wgrad.hip) 16 fragments are produced ONCE per workgroup -- input rows y-1, y, y+1 x 4
 //     channel tiles, masked by relu', and gy of row y x 4 channel tiles -- two per wave: 4 global loads, ~60 VALU for the hi / lo
 //     split, 4 ds_write_b128, into a ring of four slots (4 x 32 KB of LDS);
@@ -55,8 +55,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_split_kernel(cmf_conv_ta
   const int W = a.W, H = a.H, nsp = a.nc / 32;
   const long long xsl = a.x_sl ? a.x_sl : 16, ysl = a.y_sl ? a.y_sl : 16;
 
-  // producer role: fragments 2 wave and 2 wave + 1 of a slot.  0..11: input, row dy = f / 4, channel tile f % 4; 12..15: gy tile f - 12
-  long long lane_off[2], f_off[2];
+  // producer role: fragments 2 wave and 2 wave + 1 of a slot.  0..11: input, row dy = f / 4, channel tile f % 4; 12..15: gy tile f - 12.
+  // A producer lane (lc, lg) = (lane / 4, lane % 4) fetches columns 4 lg .. 4 lg + 3 of channel lc in BOTH slices of the pair (one
+  // 16-byte load each): in the slice-major layout the 64 lanes of a load then cover one contiguous KiB (16 channels x 64 B); with
+  // the fragment's own lane mapping (8 consecutive columns per lane, two loads) every load touched all sixteen 128-byte lines of the
+  // fragment for half of their bytes.  The values reach the fragment layout through the LDS address of the four 8-byte stores.
+  const int lc = lane >> 2, lg = lane & 3;
+  long long lane_off[2], f_off[2], sl_off[2];
   int p_dy[2];
   bool p_gy[2];
 #pragma unroll
@@ -65,10 +70,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_split_kernel(cmf_conv_ta
     p_gy[i] = f >= 12;
     p_dy[i] = p_gy[i] ? 1 : f / 4;
     const int tile = p_gy[i] ? f - 12 : f % 4;
-    const long long ch = (p_gy[i] ? co0 : ci0) + tile * 16 + r;
-    lane_off[i] = ch * (p_gy[i] ? a.y_co : a.x_ci) + (kg >> 1) * (p_gy[i] ? ysl : xsl) + 8 * (kg & 1);
+    const long long ch = (p_gy[i] ? co0 : ci0) + tile * 16 + lc;
+    lane_off[i] = ch * (p_gy[i] ? a.y_co : a.x_ci) + 4 * lg;
+    sl_off[i] = p_gy[i] ? ysl : xsl;
     f_off[i] = p_gy[i] ? 0 : ch * a.f_ci;
   }
+  // fragment lane (r, kg) holds columns 8 (kg & 1) .. + 7 of slice kg / 2: this lane's four columns of slice s are the (lg & 1) half
+  // of fragment lane (lc, 2 s + lg / 2)
+  const int st_off = (((lg >> 1) * 16 + lc) << 4) + ((lg & 1) << 3);
 
   f32x4 acc[2][9];
 #pragma unroll
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_split_kernel(cmf_conv_ta
     raw.f[i] = 1.f;
 #else
     raw.v[i][0] = *reinterpret_cast<const f32x4*>(base + lane_off[i]);
-    raw.v[i][1] = *reinterpret_cast<const f32x4*>(base + lane_off[i] + 4);
+    raw.v[i][1] = *reinterpret_cast<const f32x4*>(base + lane_off[i] + sl_off[i]);
     raw.f[i] = (HASF && !p_gy[i]) ? a.f[(long long)l_n * a.f_np + pix * a.f_px + f_off[i]] : 1.f;
 #endif
     raw.ok = (i == 0 ? 0 : raw.ok) | (ok ? 1 << i : 0);
@@ -157,9 +166,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_split_kernel(cmf_conv_ta
 #ifdef CMF_DBG_WG_NOPRODUCE
     return;
 #endif
-    unsigned char* dst = smem + slot * SLOT_BYTES + (2 * wave + i) * 2 * FRAG_BYTES + lane * 16;
-    *reinterpret_cast<u32x4*>(dst) = p_hi;
-    *reinterpret_cast<u32x4*>(dst + FRAG_BYTES) = p_lo;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned char* dst = smem + slot * SLOT_BYTES + (2 * wave + i) * 2 * FRAG_BYTES + st_off;
+    *reinterpret_cast<u32x2*>(dst) = u32x2{p_hi[0], p_hi[1]};                   // slice 0
+    *reinterpret_cast<u32x2*>(dst + 512) = u32x2{p_hi[2], p_hi[3]};             // slice 1: fragment lanes kg + 2
+    *reinterpret_cast<u32x2*>(dst + FRAG_BYTES) = u32x2{p_lo[0], p_lo[1]};
+    *reinterpret_cast<u32x2*>(dst + FRAG_BYTES + 512) = u32x2{p_lo[2], p_lo[3]};
   };
   auto produce = [&](const Raw& raw, int slot, int i) __attribute__((always_inline)) {
 #pragma unroll

@@ -16,9 +16,11 @@ from cmf_amd import engine as E
 from cmf_amd.optim import FlatOptimizer
 dev = torch.device("cuda", 0)
 cfg, schema, shape, sd, density = bench.make_model(dev)
+if schema[0]["type"] == "dequantization":                    # the noise is part of the synthetic input (as in bench.py)
+    density = density.module.density
 density.train()
 opt = FlatOptimizer(density.parameters(), opt="adam", lr=1e-4)
-x = bench.synth_batch(shape, args.batch, 0, dev)
+x = bench.synth_batch("mnist", shape, args.batch, 0, dev)
 kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=True, likelihood_wt=1., metric_wt=1.)
 
 def step():
