@@ -128,6 +128,109 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(cmf_conv_tangent_arg
   }
 }
 
+// THIN shapes: the first 3x3 conv of a coupler (1 .. 7 input channels -> 64) and its last 1x1 conv (64 -> 2 .. 16 channels).  In
+// the kernels above a wave owns whole 16-channel tiles, so these shapes keep one to four waves of a workgroup busy, on MFMA tiles
+// that are 1/16 .. 1/4 real (3x3, one input channel: 72 MFMAs per K block for 9 useful columns) -- 0.75 - 1.5 TB/s on what is a
+// pure streaming job (one pass over the 64-channel tensor).  Here
+//   * the N index of a 3x3 block is n = ci * 9 + tap (NT = ceil(9 cin / 16) tiles instead of 9 tiles of one or two real columns):
+//     lane r of tile t fetches ITS tap's pixel of ITS channel -- a per-lane address, still one 16-byte load;
+//   * all eight waves split K (wave w takes the workgroup's K blocks w, w + 8, ...) and each keeps the whole MT x NT block (at most
+//     16 accumulator tiles); the eight partial blocks are summed through LDS at the end, in a fixed order.
+template <int TAPS, int MT, int NT>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_thin_kernel(cmf_conv_tangent_args a, const float* __restrict__ gy,
+                                                                 float* __restrict__ ws, int co0, int ci0, long long nkb) {
+  extern __shared__ __attribute__((aligned(16))) float thin_part[];     // [8 waves][MT * NT tiles][256]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int W = a.W, HW = a.H * a.W, nsl = a.nc / 16;
+  const long long xsl = a.x_sl ? a.x_sl : 16, ysl = a.y_sl ? a.y_sl : 16;
+  const int fgrp = a.f_group > 1 ? a.f_group : 1;
+  const bool self = a.fmode == CMF_F_SELF_RELU;
+  const bool has_f = a.f != nullptr && a.fmode != CMF_F_NONE && !self;
+
+  long long gy_lane[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int co = co0 + mt * 16 + r;
+    gy_lane[mt] = (long long)(co < a.cout ? co : a.cout - 1) * a.y_co + 4 * q;      // rows >= cout: dropped by the reduction
+  }
+  // column n = nt * 16 + r of the block: TAPS == 9: (ci, tap) = (n / 9, n % 9); TAPS == 1: ci = n
+  long long x_lane[NT], f_lane[NT];
+  int n_dy[NT], n_dx[NT];
+  bool n_ok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + r, ci = ci0 + (TAPS == 9 ? n / 9 : n), tap = TAPS == 9 ? n % 9 : 0;
+    const int cic = ci < a.cin ? ci : a.cin - 1;
+    n_ok[nt] = ci < a.cin;
+    n_dy[nt] = TAPS == 9 ? tap / 3 - 1 : 0;
+    n_dx[nt] = TAPS == 9 ? tap % 3 - 1 : 0;
+    x_lane[nt] = (long long)cic * a.x_ci + 4 * q;
+    f_lane[nt] = (long long)cic * a.f_ci;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long long per = (nkb + gridDim.x - 1) / gridDim.x;
+  const long long kb0 = (long long)blockIdx.x * per, kb1 = kb0 + per < nkb ? kb0 + per : nkb;
+  for (long long kb = kb0 + wave; kb < kb1; kb += 8) {
+    const int sl = (int)(kb % nsl);
+    const long long t = kb / nsl;
+    const int px = (int)(t % HW), n = (int)(t / HW);
+    const int yy = px / W, xx = px - yy * W;
+    f32x4 g[MT], v[NT];
+    float m[NT];
+    bool ok[NT];
+    const float* gb = gy + (long long)n * a.y_np + (long long)px * a.y_px + sl * ysl;
+    const float* xb = a.x + (long long)n * a.x_np + sl * xsl;
+    const float* fb = has_f ? a.f + (long long)(n / fgrp) * a.f_np + (n % fgrp) : a.x;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) g[mt] = *reinterpret_cast<const f32x4*>(gb + gy_lane[mt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {                                // every load unconditional (clamped address), validity a select
+      const int y2 = yy + n_dy[nt], x2 = xx + n_dx[nt];
+      const bool in = y2 >= 0 && y2 < a.H && x2 >= 0 && x2 < W;
+      const int p2 = in ? y2 * W + x2 : px;
+      v[nt] = *reinterpret_cast<const f32x4*>(xb + (long long)p2 * a.x_px + x_lane[nt]);
+      m[nt] = has_f ? fb[(long long)p2 * a.f_px + f_lane[nt]] : 1.f;
+      ok[nt] = in && n_ok[nt];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float mj = has_f ? factor_of(m[nt], a.fmode) : 1.f;
+      f32x4 w;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = ok[nt] ? (self ? fmaxf(v[nt][k], 0.f) : v[nt][k] * mj) : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[mt][k], w[k], acc[mt][nt], 0, 0, 0);
+    }
+  }
+  // the eight partial blocks -> LDS -> summed in wave order -> ws[wg][co 64][ci 64][TAPS]
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      *reinterpret_cast<f32x4*>(thin_part + ((wave * MT * NT + mt * NT + nt) * 64 + lane) * 4) = acc[mt][nt];
+  __syncthreads();
+  float* out = ws + (size_t)blockIdx.x * 64 * 64 * TAPS;
+  for (int e = threadIdx.x; e < MT * NT * 256; e += 512) {
+    const int i = e & 3, ln = (e >> 2) & 63, tile = e >> 8;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += thin_part[(w * MT * NT + tile) * 256 + ln * 4 + i];
+    const int mt = tile / NT, nt = tile % NT, rr = ln & 15, qq = ln >> 4;
+    const int co = mt * 16 + 4 * qq + i, n = nt * 16 + rr;       // D[row = 4 q + i][col = r]
+    const int ci = TAPS == 9 ? n / 9 : n, tap = TAPS == 9 ? n % 9 : 0;
+    if (ci < 64) out[(co * 64 + ci) * TAPS + tap] = sum;
+  }
+}
+
 // 3x3 with a sliding window.  The simple kernel above issues 19 sixteen-byte loads per K block and wave, nine of them
 // for pixels the same wave loaded one and two steps earlier.  Here wave w owns output-channel tile w & 3 and
 // input-channel tiles {2 (w >> 2), 2 (w >> 2) + 1} for ALL nine taps, walks along image rows, and keeps four image
@@ -333,6 +436,32 @@ extern "C" int cmf_conv_tangent_wgrad(const cmf_conv_tangent_args* a, const floa
   const long long units = (a->taps == 9 && !simple) ? nrows : nkb;
   const int grid = (int)(units < WG_MAX ? units : WG_MAX);
   hipStream_t s = (hipStream_t)stream;
+  // thin shapes (first 3x3 / last 1x1 conv of a coupler): all eight waves on K, n = ci * 9 + tap
+  const bool thin_in = a->taps == 9 && a->cin * 9 <= 64 && !simple, thin_out = a->taps == 1 && a->cout <= 16;
+  if (thin_in || thin_out) {
+    const int nt = thin_in ? (a->cin * 9 + 15) / 16 : 4;
+    const void* fn = thin_out ? (const void*)conv_wgrad_thin_kernel<1, 1, 4>
+                   : nt == 1 ? (const void*)conv_wgrad_thin_kernel<9, 4, 1>
+                   : nt == 2 ? (const void*)conv_wgrad_thin_kernel<9, 4, 2>
+                             : (const void*)conv_wgrad_thin_kernel<9, 4, 4>;
+    const int tiles = thin_out ? 4 : 4 * (nt == 3 ? 4 : nt);
+    const int lds = 8 * tiles * 256 * (int)sizeof(float);
+    const hipError_t e = cmf_set_dynamic_lds(fn, lds);
+    if (e != hipSuccess) return (int)e;
+    const int tgrid = (int)(nkb < 8 * WG_MAX ? (nkb + 7) / 8 : WG_MAX);
+    for (int co0 = 0; co0 < a->cout; co0 += 64)
+      for (int ci0 = 0; ci0 < a->cin; ci0 += 64) {
+        if (thin_out) hipLaunchKernelGGL((conv_wgrad_thin_kernel<1, 1, 4>), dim3(tgrid), dim3(512), lds, s, *a, gy, ws, co0, ci0, nkb);
+        else if (nt == 1) hipLaunchKernelGGL((conv_wgrad_thin_kernel<9, 4, 1>), dim3(tgrid), dim3(512), lds, s, *a, gy, ws, co0, ci0, nkb);
+        else if (nt == 2) hipLaunchKernelGGL((conv_wgrad_thin_kernel<9, 4, 2>), dim3(tgrid), dim3(512), lds, s, *a, gy, ws, co0, ci0, nkb);
+        else hipLaunchKernelGGL((conv_wgrad_thin_kernel<9, 4, 4>), dim3(tgrid), dim3(512), lds, s, *a, gy, ws, co0, ci0, nkb);
+        CMF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cmf_ceil_div(64 * 64 * a->taps, 256)), dim3(256), 0, s, ws, dw, tgrid,
+                           a->taps, co0, ci0, a->cout, a->cin);
+        CMF_LAUNCH_CHECK();
+      }
+    return 0;
+  }
   for (int co0 = 0; co0 < a->cout; co0 += 64)
     for (int ci0 = 0; ci0 < a->cin; ci0 += 64) {
       if (a->taps == 9 && !simple && a->fmode == CMF_F_SELF_RELU)

@@ -44,6 +44,7 @@ by = E.TIMER.by_name() if hasattr(E.TIMER, "by_name") else {}
 E.TIMER = None
 print(f"train step B={args.batch}: {1e3*dt:.1f} ms  ({args.batch/dt:.1f} samples/s, {1/dt:.3f} steps/s)  loss {float(loss.detach()):.1f}  "
       f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
-rows = sorted(by.items(), key=lambda kv: -kv[1][1])[:12] if by else []
+rows = [kv for kv in sorted(by.items(), key=lambda kv: -kv[1][1]) if kv[1][1] / args.steps >= 0.2] if by else []
+print(f"  timed kernels in all: {sum(v[1] for v in by.values()) / args.steps:.1f} ms/step in {sum(v[0] for v in by.values()) // args.steps} launches")
 for name, (n, ms, fl, _) in rows:
     print(f"  {name:40s} {n // args.steps:5d} launches/step  {ms/args.steps:9.2f} ms/step  {fl/max(ms,1e-9)/1e9:7.1f} TFLOP/s")
