@@ -13,5 +13,5 @@ timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pmc_write --
 python3 tools/rocprof_stats.py $out/stats $out/kernel_stats.csv > /dev/null 2>&1
 python3 tools/pmc_kernel.py --batch 128 --out $out/pmc_conv_wgrad.json --kernel "conv_wgrad3x3" --note "rocprofv3 --pmc <group> --kernel-trace -- $B (separate passes)" $out/pmc_sq $out/pmc_fetch $out/pmc_write > /dev/null 2>&1
 rm -rf $out/stats $out/pmc_sq $out/pmc_fetch $out/pmc_write
-head -6 $out/kernel_stats.csv
+grep conv_wgrad $out/kernel_stats.csv | cut -c1-200
 cat $out/pmc_conv_wgrad.json
