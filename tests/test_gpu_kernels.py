@@ -66,6 +66,8 @@ def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, monke
 @pytest.mark.parametrize("cin,cout,H,W,taps,nc", [
     (64, 64, 14, 14, 9, 32), (64, 64, 6, 7, 9, 64), (128, 64, 5, 9, 9, 32), (64, 128, 28, 28, 9, 64), (2, 64, 14, 14, 9, 16), (1, 64, 8, 8, 9, 16), (64, 4, 14, 14, 1, 32),
     (128, 64, 4, 14, 9, 16), (96, 130, 3, 5, 9, 16), (17, 40, 5, 7, 9, 32), (130, 70, 1, 37, 1, 16), (10, 128, 1, 50, 1, 16),
+    # thin shapes (conv_wgrad_thin_kernel): n = ci * 9 + tap in 2 / 4 tiles, a padded output tile, three input blocks of a thin 1x1
+    (3, 64, 8, 8, 9, 16), (6, 64, 8, 8, 9, 32), (7, 24, 5, 6, 9, 16), (130, 12, 3, 9, 1, 16),
 ])
 @pytest.mark.parametrize("fmode", ["none", "relu", "tanh", "self"])
 @pytest.mark.parametrize("layout", ["panel", "slice"])
@@ -76,7 +78,7 @@ def test_conv_tangent_weight_gradient(cin, cout, H, W, taps, nc, fmode, layout, 
     from cmf_amd import engine as E
     if precision == "bf16x3" and not (taps == 9 and cin % 64 == 0 and cout % 64 == 0 and nc % 32 == 0 and fmode in ("none", "relu", "self")):
         pytest.skip("not covered by the split-precision weight-gradient kernel (the engine uses the fp32 one)")
-    if layout == "slice" and cin not in (64, 2, 128, 17):
+    if layout == "slice" and cin not in (64, 2, 128, 17, 6):
         pytest.skip("slice-major layout: a subset of the shapes is enough")
     gen = torch.Generator().manual_seed(cin * 1000 + cout + H)
     B, HW, k = 3, H * W, 3 if taps == 9 else 1
