@@ -111,7 +111,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   constexpr bool SELF = MODE == 2, RELU = MODE == 1, BITS = MODE == 3;   // 3 = relu' from a bit mask (CMF_F_RELU_BITS)
   // 4 = PLAIN: no input factor at all (no factor stream, like SELF, and no relu) and an optional OUTPUT-side relu' bit mask
   // applied at the store -- the reverse (cotangent) sweep: the adjoint of "mask, then conv" is "transposed conv, then mask"
-  constexpr bool PLAIN = MODE == 4;
+  constexpr bool PLAIN = MODE == 4 || MODE == 5;
+  constexpr bool INPLACE = MODE == 5;                          // PLAIN with the output tensor as the (unmasked) residual: below
   constexpr bool NOF = SELF || PLAIN;                            // no factor stream
   constexpr int NF = NOF ? 0 : BITS ? 1 : 8;                     // factor loads per loader thread and chunk
   using C = BCfg<COT, PXW>;
@@ -527,8 +528,11 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     const unsigned long long u = reinterpret_cast<unsigned long long>(a.y + (long long)np * a.y_np + (long long)slice * (a.y_sl ? a.y_sl : 16) + (long long)cog * 64 * y_co);
     const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
     const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, -1, RS_FLAGS);
+    // num_records 0x7fffff00: every real offset (a lane's channel / column term, far below 2^31) passes the range check, the
+    // offset Y_DROP of a masked-off lane of an in-place store does not -- its store is discarded, still counted by vmcnt
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffff00, RS_FLAGS);
   };
+  constexpr int Y_DROP = 0x7ffffff0;
   auto r_rsrc = [&](int np, int slice, int cog, bool on) {         // words, for the inline-asm loads
     const float* base = a.r ? a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) + (long long)cog * 64 * r_co : a.y;
     const unsigned long long u = reinterpret_cast<unsigned long long>(base);
@@ -569,13 +573,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // hand-counted waits (wait_res below): hipcc's vmcnt for these loads also counted the interleaved stores'
   // completion, so chunk 0 of every item stalled on HBM round trips.
   auto init_pixel = [&](const Item& it, const i32x4& rrs_in, int p) __attribute__((always_inline)) {
-#ifdef CMF_DBG_STAMP                               // the stamp code's divergent branches push the descriptor into VGPRs
+    // hipcc moves a loop-carried descriptor into VGPRs as soon as a lane-dependent select sits near it (the stamp code, the
+    // in-place store's offset select) and does not bring an "s"-constrained vector operand back by itself: readfirstlane is a
+    // plain copy when the words already are scalars
     i32x4 rrs;
 #pragma unroll
     for (int i = 0; i < 4; ++i) rrs[i] = __builtin_amdgcn_readfirstlane(rrs_in[i]);
-#else
-    const i32x4& rrs = rrs_in;
-#endif
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       const int so = it.rpix + 4 * (((p / C::TW) * a.W + p % C::TW) * r_px + c * 16 * r_co);
@@ -589,6 +592,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // unconditional (the launcher points a missing mask at the input tensor and clears fomode): no divergent paths here.
   unsigned omask[PW];
   const bool use_omask = PLAIN && a.fomode == CMF_F_RELU_BITS;
+  // IN-PLACE skip connection of the reverse sweep,  y <- y + mask . conv(x):  the residual IS the output tensor (launcher: same
+  // pointer and strides).  The accumulators start from it as usual, and at the store a lane whose (pixel, channel) is masked off
+  // keeps what is in memory -- its store goes past the descriptor's range -- while the others write residual + product.  (The
+  // residual as a separate tensor would have to be re-read at the store: the accumulators hold residual + product by then.)
+  constexpr bool inplace = INPLACE;                            // launcher: a.r == a.y with y's strides, bit mask given
+  // (compile-time: as a run-time flag the 4 x 8-tile PLAIN variant spilled 15 VGPRs)
   auto load_omask = [&](const Item& it) __attribute__((always_inline)) {
     if constexpr (PLAIN) {
       const unsigned long long base = reinterpret_cast<unsigned long long>(a.fo) + (unsigned long long)it.np * a.fo_np +
@@ -610,12 +619,14 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       f32x4 v = acc[p][c];
+      int vo = yvoff;
       if constexpr (PLAIN) {
         const bool on = (omask[p] >> (c * 16 + cl)) & 1u;
-        v = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (inplace) vo = on ? yvoff : Y_DROP;
+        else v = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       v += bias[c];                                                // per-channel constant (primal bias)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, v), cur_yrs, yvoff,
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, v), cur_yrs, vo,
                                              it.ypix + 4 * (((p / C::TW) * a.W + p % C::TW) * y_px + c * 16 * y_co), 0);
     }
   };
@@ -836,6 +847,10 @@ int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
   if (a.fmode == CMF_F_SELF_RELU) return (a.cout > 32) ? launch<4, PXW, 2>(a, s) : launch<2, PXW, 2>(a, s);
   if (a.fmode == CMF_F_RELU) return (a.cout > 32) ? launch<4, PXW, 1>(a, s) : launch<2, PXW, 1>(a, s);
   if (a.fmode == CMF_F_RELU_BITS) return (a.cout > 32) ? launch<4, PXW, 3>(a, s) : launch<2, PXW, 3>(a, s);
+  if (a.fmode == CMF_F_NONE && a.fo && a.r) {                   // in-place skip connection: 2 x 14 tiles, 64-channel groups only
+    if constexpr (PXW == 7) return launch<4, PXW, 5>(a, s);
+    else return CMF_EINVAL;
+  }
   if (a.fmode == CMF_F_NONE) return (a.cout > 32) ? launch<4, PXW, 4>(a, s) : launch<2, PXW, 4>(a, s);
   return (a.cout > 32) ? launch<4, PXW, 0>(a, s) : launch<2, PXW, 0>(a, s);
 }
@@ -867,7 +882,10 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   if (a.fo) {
     // output-side factor: only as a relu' BIT MASK, without input factor and without residual (the residual is the
     // accumulators' initial value and would be masked with the product), whole groups of 64 output channels
-    if (a.fmode != CMF_F_NONE || a.fomode != CMF_F_RELU_BITS || a.r || a.cout % 64) return CMF_EINVAL;
+    // -- unless the residual IS the output tensor (the in-place skip connection: masked-off lanes keep what is in memory)
+    const bool inplace = a.r == a.y && a.r_np == a.y_np && a.r_co == a.y_co && a.r_px == a.y_px && a.r_sl == a.y_sl;
+    if (a.fmode != CMF_F_NONE || a.fomode != CMF_F_RELU_BITS || (a.r && !inplace) || a.cout % 64) return CMF_EINVAL;
+    if (a.r && a.bias) return CMF_EINVAL;
     if (a.fo_np % 4 || (uintptr_t)a.fo % 4 || a.fo_np < (long long)a.H * a.W * (a.cout / 8)) return CMF_EINVAL;
   }
   if (a.fmode == CMF_F_RELU_BITS && a.f_np < (long long)a.H * a.W * (a.cin / 8)) return CMF_EINVAL;
@@ -876,7 +894,8 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;    // 16-byte residual loads
   const long long HW = (long long)a.H * a.W;
   if (!fits_int((a.cin + 8) * a.x_ci + HW * a.x_px + a.nc) || !fits_int((a.cin + 8) * a.f_ci + HW * a.f_px) ||
-      !fits_int((a.cout + 64) * a.y_co + HW * a.y_px + a.nc) || (a.r && !fits_int((a.cout + 64) * a.r_co + HW * a.r_px + a.nc)) ||
+      !fits_int((a.cout + 64) * a.y_co + HW * a.y_px + a.nc + 64) ||          // + 64: below the y descriptor's 0x7fffff00 records
+      (a.r && !fits_int((a.cout + 64) * a.r_co + HW * a.r_px + a.nc)) ||
       HW > (1 << 24))
     return CMF_ERANGE;
   hipStream_t s = (hipStream_t)stream;

@@ -233,8 +233,11 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     # split-precision kernel: any input factor without output factor, or NO input factor with an optional relu' BIT MASK on the
     # output (no residual then): the transposed convs of the reverse sweep
     obits = isinstance(fo, BitMask)
+    # ... or with the residual IN PLACE (res_t is y_t at the same offset: y <- y + mask . conv(x), the reverse sweep's skip connection)
+    inplace = res_t is not None and res_t.data_ptr() == y_t.data_ptr() and int(res_off) == int(y_off)
     split = ((precision or TANGENT_PRECISION) == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
-             and ((fmode != F_NONE and fo is None) or (fmode == F_NONE and (fo is None or (obits and res_t is None and cout % 64 == 0)))))
+             and ((fmode != F_NONE and fo is None) or
+                  (fmode == F_NONE and (fo is None or (obits and (res_t is None or inplace) and cout % 64 == 0)))))
     assert not obits or split, "bit-mask output factors are applied by the split-precision kernel only"
     if obits:
         fo, fo_np, fo_co, fo_px, fomode = fo.data, fo.np_bytes, 0, 0, F_RELU_BITS
@@ -1037,14 +1040,20 @@ def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None, cross=None):
             if train:
                 conv_tangent_wgrad(hs[k].data, 0, *hd, u.data, 0, *cd, _grad_of(grads, blk.conv1.weight), 9, B, hid, hid, H, W,
                                    nc, f=a_in, x_sl=hsl, y_sl=csl, **fr)
-            if split:
+            if split and W % 14 == 0:
+                # the skip connection IN PLACE: c_h += relu'(a_in) . conv1^T(c_u) -- the kernel starts its accumulators from c_h and
+                # the lanes the mask switches off do not store (a separate accumulate pass cost 17 ms of a 235 ms step)
+                conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch.data, *cd, B, hid, hid, H, W, nc, fo=relu_bits(a_in),
+                             transpose=True, x_sl=csl, y_sl=csl, res_t=ch.data)
+            elif split:                                    # 4 x 8 tiles (CIFAR): separate accumulate pass
                 conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch2.data, *cd, B, hid, hid, H, W, nc, fo=relu_bits(a_in),
                              transpose=True, x_sl=csl, y_sl=csl)
                 accumulate(ch2.data, ch.data)
+                ch, ch2 = ch2, ch
             else:
                 conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch2.data, *cd, B, hid, hid, H, W, nc, res_t=ch.data,
                              fo=a_in, **fa, **f32)
-            ch, ch2 = ch2, ch
+                ch, ch2 = ch2, ch
         # h0 = conv0(mask . v_in)  ->  Ct[view] += mask . conv0^T(c_h0)
         off = view.chan_off * HW * nc
         m = view.mask
