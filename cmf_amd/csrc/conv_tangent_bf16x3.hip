@@ -847,7 +847,7 @@ int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
   if (a.fmode == CMF_F_SELF_RELU) return (a.cout > 32) ? launch<4, PXW, 2>(a, s) : launch<2, PXW, 2>(a, s);
   if (a.fmode == CMF_F_RELU) return (a.cout > 32) ? launch<4, PXW, 1>(a, s) : launch<2, PXW, 1>(a, s);
   if (a.fmode == CMF_F_RELU_BITS) return (a.cout > 32) ? launch<4, PXW, 3>(a, s) : launch<2, PXW, 3>(a, s);
-  if (a.fmode == CMF_F_NONE && a.fo && a.r) {                   // in-place skip connection: 2 x 14 tiles, 64-channel groups only
+  if (a.fmode == CMF_F_NONE && a.fomode == CMF_F_RELU_BITS && a.r) {   // in-place skip connection: 2 x 14 tiles, 64-channel groups only
     if constexpr (PXW == 7) return launch<4, PXW, 5>(a, s);
     else return CMF_EINVAL;
   }
