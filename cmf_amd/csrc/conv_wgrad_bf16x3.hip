@@ -65,7 +65,7 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 struct Raw4 {
   f32x4 v[4][2];
   float f[4];
-  int ok;
+  bool ok;                                           // wave-uniform: column and row inside the image
 };
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_tangent_args a, const float* __restrict__ gy,
@@ -105,59 +105,49 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_ta
     // reach the fragment layout (lane (r, kg): columns 8 (kg & 1) .. + 7 of slice kg / 2) through the LDS address of the four 8-byte
     // stores: this lane's columns of slice s are the (lg & 1) half of fragment lane (lc, 2 s + lg / 2).
     const int lc = lane >> 2, lg = lane & 3;
-    long long lane_off[4], f_off[4], sl_off[4];
-    int p_dy[4];
-    bool p_gy[4];
+    // the four fragments of a producer wave are the four channel tiles of ONE tensor row: waves 4..6 the input rows y-1, y, y+1
+    // (fragments 0..11 = row dy x tile), wave 7 the gy row (fragments 12..15) -- so the row state below is per wave, not per fragment
+    const bool is_gy = pw == 3;
+    const int dy = is_gy ? 1 : pw;
+    const long long sl_off = is_gy ? ysl : xsl;
+    const int px_step = (int)(is_gy ? a.y_px : a.x_px), f_px = (int)a.f_px;
+    long long lane_off[4], f_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int f = 4 * pw + i;                       // 0..11: input, row dy = f / 4, channel tile f % 4; 12..15: gy tile f - 12
-      p_gy[i] = f >= 12;
-      p_dy[i] = p_gy[i] ? 1 : f / 4;
-      const int tile = p_gy[i] ? f - 12 : f % 4;
-      const long long ch = (p_gy[i] ? co0 : ci0) + tile * 16 + lc;
-      lane_off[i] = ch * (p_gy[i] ? a.y_co : a.x_ci) + 4 * lg;
-      sl_off[i] = p_gy[i] ? ysl : xsl;
-      f_off[i] = p_gy[i] ? 0 : ch * a.f_ci;
+      const long long ch = (is_gy ? co0 : ci0) + i * 16 + lc;
+      lane_off[i] = ch * (is_gy ? a.y_co : a.x_ci) + 4 * lg;
+      f_off[i] = ch * a.f_ci;
     }
     const int st_off = (((lg >> 1) * 16 + lc) << 4) + ((lg & 1) << 3);
     // Producer instruction count is what bounds this kernel (stamps: an MFMA wave computes 2350 cycles of a 4000-cycle step and
     // waits for the producers the rest of it): everything that only changes with the image row -- the row decode with its
-    // integer divisions, the 64-bit row bases, the row validity -- is recomputed at a row change only (a uniform branch), and the
+    // integer divisions, the 64-bit row base, the row validity -- is recomputed at a row change only (a uniform branch), and the
     // relu' / validity mask is ONE select per value (a lane's eight values belong to one channel of one pixel).
     int l_slot = 0, l_col = -1, l_rid = xstart + jx;
-    const float* rbase[4];
-    const float* fbase[4];
-    int px_step[4];
-    int row_ok = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) px_step[i] = (int)(p_gy[i] ? a.y_px : a.x_px), rbase[i] = a.x, fbase[i] = a.f;
-    const int f_px = (int)a.f_px;
+    const float* rbase = a.x;
+    const float* fbase = a.f;
+    bool row_ok = false;
     auto set_row = [&]() __attribute__((always_inline)) {
       const int yy = l_rid % H, t = l_rid / H, sp = t % nsp, n = t / nsp;
-      row_ok = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int y2 = yy + p_dy[i] - 1;
-        const long long rowpix = (long long)(y2 < 0 ? 0 : y2 >= H ? H - 1 : y2) * W;
-        rbase[i] = p_gy[i] ? gy + (long long)n * a.y_np + rowpix * a.y_px + 2 * sp * ysl
-                           : a.x + (long long)n * a.x_np + rowpix * a.x_px + 2 * sp * xsl;
-        if (HASF) fbase[i] = a.f + (long long)n * a.f_np + rowpix * a.f_px;
-        row_ok |= (y2 >= 0 && y2 < H) ? 1 << i : 0;
-      }
+      const int y2 = yy + dy - 1;
+      const long long rowpix = (long long)(y2 < 0 ? 0 : y2 >= H ? H - 1 : y2) * W;
+      rbase = is_gy ? gy + (long long)n * a.y_np + rowpix * a.y_px + 2 * sp * ysl
+                    : a.x + (long long)n * a.x_np + rowpix * a.x_px + 2 * sp * xsl;
+      if (HASF) fbase = a.f + (long long)n * a.f_np + rowpix * a.f_px;
+      row_ok = y2 >= 0 && y2 < H;
     };
     if (my_rows > 0) set_row();
     auto fetch = [&](Raw4& raw) __attribute__((always_inline)) {
       const bool alive = l_slot < nslots;
-      const bool colok = alive && l_col >= 0 && l_col < W;
       const int colc = l_col < 0 ? 0 : l_col >= W ? W - 1 : l_col;
+      const float* base = rbase + colc * px_step;                  // 32-bit product: W * pixel stride < 2^31 (launcher)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* base = rbase[i] + colc * px_step[i];          // 32-bit product: W * pixel stride < 2^31 (launcher)
+      for (int i = 0; i < 4; ++i) {                                // every load unconditional (clamped address), validity a select
         raw.v[i][0] = *reinterpret_cast<const f32x4*>(base + lane_off[i]);
-        raw.v[i][1] = *reinterpret_cast<const f32x4*>(base + lane_off[i] + sl_off[i]);
-        raw.f[i] = (HASF && !p_gy[i]) ? fbase[i][colc * f_px + f_off[i]] : 1.f;
+        raw.v[i][1] = *reinterpret_cast<const f32x4*>(base + lane_off[i] + sl_off);
+        raw.f[i] = (HASF && !is_gy) ? fbase[colc * f_px + f_off[i]] : 1.f;
       }
-      raw.ok = colok ? row_ok : 0;
+      raw.ok = alive && l_col >= 0 && l_col < W && row_ok;
       const bool more = alive && l_slot + 1 < nslots;              // past the end the cursor stays put
       l_slot += alive ? 1 : 0;
       if (more && l_col == W - 1) {                                // row change (wave-uniform)
@@ -172,12 +162,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_ta
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const bool on = ((raw.ok >> i) & 1) && (!(HASF && !p_gy[i]) || raw.f[i] > 0.f);
+        const bool on = raw.ok && (!(HASF && !is_gy) || raw.f[i] > 0.f);
         unsigned hi[4], lo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float e = raw.v[i][j >> 1][(2 * j) & 3], o = raw.v[i][j >> 1][(2 * j + 1) & 3];
-          if (SELF && !p_gy[i]) e = fmaxf(e, 0.f), o = fmaxf(o, 0.f);
+          if (SELF && !is_gy) e = fmaxf(e, 0.f), o = fmaxf(o, 0.f);
           e = on ? e : 0.f, o = on ? o : 0.f;
           const unsigned hb = pack2(e, o);
           hi[j] = hb;
