@@ -207,14 +207,15 @@ def pmc_traffic(precision, B):
                                                 f"scaled to per_gpu_batch={B}; not collected by this run")
 
 
-def train_bench(args, density, x, B, rank, world, device):
-    """Secondary metric: training samples / s (one process per GPU, flat gradient all-reduce over RCCL, fused Adam)."""
+def train_bench(args, density, x, B, rank, world, device, off=True):
+    """Secondary metric: training samples / s (one process per GPU, flat gradient all-reduce over RCCL, fused Adam).  C3: the
+    Cholesky objective with the off-diagonal metric term; C5: train mode selects the Hutchinson + CG surrogate (non_square.py:131-138)."""
     import torch
     import torch.distributed as dist
     from cmf_amd.optim import FlatOptimizer
     density.train()
     opt = FlatOptimizer(density.parameters(), opt="adam", lr=1e-4)
-    kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=True, likelihood_wt=1., metric_wt=1.)
+    kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=off, likelihood_wt=1., metric_wt=1.)
 
     def step():
         opt.zero_grad()
@@ -242,11 +243,14 @@ def train_bench(args, density, x, B, rank, world, device):
     dt = float(dt.item())
     if rank == 0:
         print(json.dumps({
-            "metric": "training samples/sec (forward + backward + Adam, JtJ-cholesky objective), MNIST D=784 d=64", "value": B * world * args.steps / dt,
+            "metric": ("training samples/sec (forward + backward + Adam, JtJ-cholesky objective), MNIST D=784 d=64" if args.config == "c3" else
+                       f"training samples/sec (forward + backward + Adam), {METRICS[args.config].split(', ', 1)[1]}"),
+            "value": B * world * args.steps / dt,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (3x3 tangent convs, their transposes and weight gradients as bf16x3 split MFMA, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": "C3 / C4 model, one optimiser step per batch, g_ij off-diagonal objective", "per_gpu_batch": B,
+            "config": {"workload": ("C3 / C4 model, one optimiser step per batch, g_ij off-diagonal objective" if args.config == "c3" else
+                                    CONFIGS[args.config][4] + ", one optimiser step per batch, train-mode objective"), "per_gpu_batch": B,
                        "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss),
                        "peak_memory_gib": torch.cuda.max_memory_allocated(device) / 2 ** 30}}), flush=True)
     if world > 1:
@@ -318,7 +322,7 @@ def run_rank(args):
         density.train()                                      # non_square.py:131-138: train mode selects hutch_with_cg
 
     if args.train:
-        return train_bench(args, inner, x, B, rank, world, device)
+        return train_bench(args, inner, x, B, rank, world, device, off)
 
     graph = None
     if args.graph:
