@@ -597,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // keeps what is in memory -- its store goes past the descriptor's range -- while the others write residual + product.  (The
   // residual as a separate tensor would have to be re-read at the store: the accumulators hold residual + product by then.)
   constexpr bool inplace = INPLACE;                            // launcher: a.r == a.y with y's strides, bit mask given
-  // (compile-time: as a run-time flag the 4 x 8-tile PLAIN variant spilled 15 VGPRs)
+  // (compile-time: as a run-time flag the 4 x 8-tile PLAIN variant spilled 15 VGPRs; 252 / 244 VGPRs this way)
   auto load_omask = [&](const Item& it) __attribute__((always_inline)) {
     if constexpr (PLAIN) {
       const unsigned long long base = reinterpret_cast<unsigned long long>(a.fo) + (unsigned long long)it.np * a.fo_np +
@@ -847,9 +847,8 @@ int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
   if (a.fmode == CMF_F_SELF_RELU) return (a.cout > 32) ? launch<4, PXW, 2>(a, s) : launch<2, PXW, 2>(a, s);
   if (a.fmode == CMF_F_RELU) return (a.cout > 32) ? launch<4, PXW, 1>(a, s) : launch<2, PXW, 1>(a, s);
   if (a.fmode == CMF_F_RELU_BITS) return (a.cout > 32) ? launch<4, PXW, 3>(a, s) : launch<2, PXW, 3>(a, s);
-  if (a.fmode == CMF_F_NONE && a.fomode == CMF_F_RELU_BITS && a.r) {   // in-place skip connection: 2 x 14 tiles, 64-channel groups only
-    if constexpr (PXW == 7) return launch<4, PXW, 5>(a, s);
-    else return CMF_EINVAL;
+  if (a.fmode == CMF_F_NONE && a.fomode == CMF_F_RELU_BITS && a.r) {   // in-place skip connection: 64-channel groups only
+    return launch<4, PXW, 5>(a, s);
   }
   if (a.fmode == CMF_F_NONE) return (a.cout > 32) ? launch<4, PXW, 4>(a, s) : launch<2, PXW, 4>(a, s);
   return (a.cout > 32) ? launch<4, PXW, 0>(a, s) : launch<2, PXW, 0>(a, s);

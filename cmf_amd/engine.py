@@ -1040,16 +1040,11 @@ def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None, cross=None):
             if train:
                 conv_tangent_wgrad(hs[k].data, 0, *hd, u.data, 0, *cd, _grad_of(grads, blk.conv1.weight), 9, B, hid, hid, H, W,
                                    nc, f=a_in, x_sl=hsl, y_sl=csl, **fr)
-            if split and W % 14 == 0:
+            if split:
                 # the skip connection IN PLACE: c_h += relu'(a_in) . conv1^T(c_u) -- the kernel starts its accumulators from c_h and
                 # the lanes the mask switches off do not store (a separate accumulate pass cost 17 ms of a 235 ms step)
                 conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch.data, *cd, B, hid, hid, H, W, nc, fo=relu_bits(a_in),
                              transpose=True, x_sl=csl, y_sl=csl, res_t=ch.data)
-            elif split:                                    # 4 x 8 tiles (CIFAR): separate accumulate pass
-                conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch2.data, *cd, B, hid, hid, H, W, nc, fo=relu_bits(a_in),
-                             transpose=True, x_sl=csl, y_sl=csl)
-                accumulate(ch2.data, ch.data)
-                ch, ch2 = ch2, ch
             else:
                 conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch2.data, *cd, B, hid, hid, H, W, nc, res_t=ch.data,
                              fo=a_in, **fa, **f32)

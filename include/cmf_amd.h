@@ -106,8 +106,7 @@ int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
  * cmf_pack_weight_bf16x3 (out == NULL: size query in bytes through *out_bytes).  Output-side factor: only with
  * fmode CMF_F_NONE, no residual, cout % 64 == 0 and fomode CMF_F_RELU_BITS -- fo is then a relu' bit mask over the OUTPUT
  * channels (byte np*fo_np + px*(cout/8) + co/8, fo_np in bytes; written by cmf_relu_bits or mask_out): the transposed convs of
- * the reverse sweep.  A residual is accepted together with that bit mask only IN PLACE (r == y with y's strides, W % 14 == 0, no
- * bias):  y <- y + Fo . conv(x)  -- the skip connection of the reverse sweep; entries the mask switches off are not written at all
+ * the reverse sweep.  A residual is accepted together with that bit mask only IN PLACE (r == y with y's strides, no bias):  y <- y + Fo . conv(x)  -- the skip connection of the reverse sweep; entries the mask switches off are not written at all
  * (they keep their bits).  mask_out is not supported. */
 int cmf_pack_weight_bf16x3(const float* w, void* out, int cout, int cin, long long* out_bytes, void* stream);
 int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* a, void* stream);
