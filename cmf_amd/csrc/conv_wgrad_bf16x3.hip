@@ -22,7 +22,9 @@
 // MFMA waves computing 2350 cycles of a 4000-cycle step and waiting for the producers the rest: the kernel is bound by the
 // producers' INSTRUCTION COUNT.  Row-invariant work hoisted to the row change and one select per value instead of a multiply and
 // a select: 560 -> 400 instructions per producer step, both roles at ~2400 cycles per step, 344 TFLOP/s.
-// Shapes: taps = 9, cin % 64 == 0, cout % 64 == 0, nc % 32 == 0, factor NONE, RELU from a float tensor or SELF_RELU; everything else
+// Shapes: taps = 9, cin % 64 == 0, cout % 64 == 0, nc % 32 == 0, factor NONE, RELU from a float tensor or from a bit mask
+// (CMF_F_RELU_BITS: one byte per (sample, pixel, 8 channels) -- a fragment's sixteen masks are two neighbouring bytes, where the
+// float form touches sixteen cache lines), or SELF_RELU; everything else
 // stays on the fp32 kernel.  Partial blocks and their fixed-order reduction are shared with conv_wgrad.hip.
 #include "common.h"
 #include <type_traits>
@@ -70,7 +72,7 @@ struct Raw4 {
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_tangent_args a, const float* __restrict__ gy,
                                                                      float* __restrict__ ws, int co0, int ci0, int nrows) {
-  constexpr bool HASF = MODE == 1, SELF = MODE == 2;
+  constexpr bool BITS = MODE == 3, HASF = MODE == 1 || BITS, SELF = MODE == 2;   // BITS: relu' from a bit mask (CMF_F_RELU_BITS)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -110,14 +112,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_ta
     const bool is_gy = pw == 3;
     const int dy = is_gy ? 1 : pw;
     const long long sl_off = is_gy ? ysl : xsl;
-    const int px_step = (int)(is_gy ? a.y_px : a.x_px), f_px = (int)a.f_px;
+    const int px_step = (int)(is_gy ? a.y_px : a.x_px), f_px = BITS ? a.cin / 8 : (int)a.f_px;   // BITS: bytes per pixel
     long long lane_off[4], f_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long ch = (is_gy ? co0 : ci0) + i * 16 + lc;
       lane_off[i] = ch * (is_gy ? a.y_co : a.x_ci) + 4 * lg;
-      f_off[i] = ch * a.f_ci;
+      f_off[i] = BITS ? ch >> 3 : ch * a.f_ci;       // BITS: byte of the channel's octet inside the pixel's cin / 8 bytes
     }
+    const int f_bit = lc & 7;                        // ... and the channel's bit in it (channel tiles start at multiples of 16)
     const int st_off = (((lg >> 1) * 16 + lc) << 4) + ((lg & 1) << 3);
     // Producer instruction count is what bounds this kernel (stamps: an MFMA wave computes 2350 cycles of a 4000-cycle step and
     // waits for the producers the rest of it): everything that only changes with the image row -- the row decode with its
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_ta
       const long long rowpix = (long long)(y2 < 0 ? 0 : y2 >= H ? H - 1 : y2) * W;
       rbase = is_gy ? gy + (long long)n * a.y_np + rowpix * a.y_px + 2 * sp * ysl
                     : a.x + (long long)n * a.x_np + rowpix * a.x_px + 2 * sp * xsl;
-      if (HASF) fbase = a.f + (long long)n * a.f_np + rowpix * a.f_px;
+      if (BITS) fbase = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.f) + (long long)n * a.f_np + rowpix * f_px);
+      else if (HASF) fbase = a.f + (long long)n * a.f_np + rowpix * a.f_px;
       row_ok = y2 >= 0 && y2 < H;
     };
     if (my_rows > 0) set_row();
@@ -145,7 +149,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_ta
       for (int i = 0; i < 4; ++i) {                                // every load unconditional (clamped address), validity a select
         raw.v[i][0] = *reinterpret_cast<const f32x4*>(base + lane_off[i]);
         raw.v[i][1] = *reinterpret_cast<const f32x4*>(base + lane_off[i] + sl_off);
-        raw.f[i] = (HASF && !is_gy) ? fbase[colc * f_px + f_off[i]] : 1.f;
+        if (BITS && !is_gy) {                                      // the raw byte; decoded in produce (touching it here would wait for the load)
+          raw.f[i] = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned char*>(fbase)[colc * f_px + f_off[i]]);
+        } else {
+          raw.f[i] = (HASF && !is_gy) ? fbase[colc * f_px + f_off[i]] : 1.f;
+        }
       }
       raw.ok = alive && l_col >= 0 && l_col < W && row_ok;
       const bool more = alive && l_slot + 1 < nslots;              // past the end the cursor stays put
@@ -162,7 +170,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_ta
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const bool on = raw.ok && (!(HASF && !is_gy) || raw.f[i] > 0.f);
+        const bool fon = BITS ? ((__builtin_bit_cast(unsigned, raw.f[i]) >> f_bit) & 1u) != 0 : raw.f[i] > 0.f;
+        const bool on = raw.ok && (!(HASF && !is_gy) || fon);
         unsigned hi[4], lo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -298,8 +307,9 @@ extern "C" int cmf_conv_tangent_wgrad_bf16x3(const cmf_conv_tangent_args* a, con
   if (!a || !a->x || !gy || !dw || !ws) return CMF_EINVAL;
   if (a->taps != 9 || a->cin % 64 || a->cout % 64 || a->nc <= 0 || a->nc % 32) return CMF_EINVAL;
   if (a->np <= 0 || a->H <= 0 || a->W <= 0) return CMF_EINVAL;
-  if (a->fmode != CMF_F_NONE && a->fmode != CMF_F_RELU && a->fmode != CMF_F_SELF_RELU) return CMF_EINVAL;
-  if (a->fmode == CMF_F_RELU && (!a->f || a->f_group > 1)) return CMF_EINVAL;
+  if (a->fmode != CMF_F_NONE && a->fmode != CMF_F_RELU && a->fmode != CMF_F_SELF_RELU && a->fmode != CMF_F_RELU_BITS) return CMF_EINVAL;
+  if ((a->fmode == CMF_F_RELU || a->fmode == CMF_F_RELU_BITS) && (!a->f || a->f_group > 1)) return CMF_EINVAL;
+  if (a->fmode == CMF_F_RELU_BITS && a->f_np < (long long)a->H * a->W * (a->cin / 8)) return CMF_EINVAL;   // f_np in bytes
   if (ws_bytes < (long long)WG_MAX * 64 * 64 * 9 * (long long)sizeof(float)) return CMF_EINVAL;
   if (((uintptr_t)a->x | (uintptr_t)gy) % 16 || (a->x_np | a->x_ci | a->x_px | a->x_sl | a->y_np | a->y_co | a->y_px | a->y_sl) % 4)
     return CMF_EINVAL;
@@ -313,11 +323,14 @@ extern "C" int cmf_conv_tangent_wgrad_bf16x3(const cmf_conv_tangent_args* a, con
     hipError_t e = cmf_set_dynamic_lds((const void*)conv_wgrad3x3_roles_kernel<0>, LDS_BYTES);
     if (e == hipSuccess) e = cmf_set_dynamic_lds((const void*)conv_wgrad3x3_roles_kernel<1>, LDS_BYTES);
     if (e == hipSuccess) e = cmf_set_dynamic_lds((const void*)conv_wgrad3x3_roles_kernel<2>, LDS_BYTES);
+    if (e == hipSuccess) e = cmf_set_dynamic_lds((const void*)conv_wgrad3x3_roles_kernel<3>, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
   }
   for (int co0 = 0; co0 < a->cout; co0 += 64)
     for (int ci0 = 0; ci0 < a->cin; ci0 += 64) {
-      if (a->fmode == CMF_F_RELU)
+      if (a->fmode == CMF_F_RELU_BITS)
+        hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<3>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
+      else if (a->fmode == CMF_F_RELU)
         hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<1>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
       else if (a->fmode == CMF_F_SELF_RELU)
         hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<2>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);

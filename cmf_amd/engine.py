@@ -274,6 +274,9 @@ def conv_tangent_wgrad(x_t, x_off, x_np, x_ci, x_px, gy_t, gy_off, y_np, y_co, y
     assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * cin * taps
     a = ConvTangentArgs()
     a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
+    fbits = isinstance(f, BitMask)                                   # relu' as a bit mask: the split kernel only
+    if fbits:
+        f, f_np, f_ci, f_px, fmode = f.data, f.np_bytes, 0, 0, F_RELU_BITS
     a.f = _p(f); a.f_np, a.f_ci, a.f_px = int(f_np), int(f_ci), int(f_px); a.fmode = fmode
     a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
     a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), int(taps)
@@ -287,7 +290,8 @@ def conv_tangent_wgrad(x_t, x_off, x_np, x_ci, x_px, gy_t, gy_off, y_np, y_co, y
     gy = C.c_void_p(gy_t.data_ptr() + 4 * int(gy_off))
     # split-precision kernel (operands shared through LDS) where the forward convs use one: whole 64-channel blocks, column pairs
     split = ((precision or TANGENT_PRECISION) == "bf16x3" and taps == 9 and cin % 64 == 0 and cout % 64 == 0 and nc % 32 == 0
-             and fmode in (F_NONE, F_RELU, F_SELF_RELU) and f_group <= 1)
+             and fmode in (F_NONE, F_RELU, F_SELF_RELU, F_RELU_BITS) and f_group <= 1)
+    assert not fbits or split, "bit-mask factors are read by the split-precision weight-gradient kernel only"
     fn, what = (lib.cmf_conv_tangent_wgrad_bf16x3, "cmf_conv_tangent_wgrad_bf16x3") if split else \
                (lib.cmf_conv_tangent_wgrad, "cmf_conv_tangent_wgrad")
     launch = lambda: _lib.check(fn(C.byref(a), gy, _p(dw), _p(ws), need, _stream()), what)
@@ -1024,26 +1028,30 @@ def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None, cross=None):
         # y = convf(relu'(a_last) . h)  ->  c_h = relu'(a_last) . convf^T(c_y)
         ch = new(hid)
         conv_tangent(YC.data, 0, *pn(cout), convf.weight, 1, ch.data, *cd, B, cout, hid, H, W, nc, fo=acts[-1], y_sl=csl, **fa, **f32)
-        u, ch2 = new(hid), new(hid)
+        u, ch2 = new(hid), (None if split else new(hid))      # the in-place skip connection needs no second cotangent buffer
         for k in reversed(range(len(blocks))):
             blk, a_in, c1 = blocks[k], acts[2 * k], acts[2 * k + 1]
             # h2 = h + conv2(relu'(c1) . u), u = conv1(relu'(a_in) . h):
             #   c_u = relu'(c1) . conv2^T(c_h2);   c_h = c_h2 + relu'(a_in) . conv1^T(c_u)
+            # split kernels: relu' of both activations as bit masks, shared by the weight gradients (input factor) and the
+            # transposed convs (output mask)
+            b_c1, b_in = (relu_bits(c1), relu_bits(a_in)) if split else (None, None)
+            wf = lambda act, bits: dict(f=bits) if split and nc % 32 == 0 else dict(f=act, **fr)   # (the fp32 kernel reads floats)
             if train:
                 conv_tangent_wgrad(us[k].data, 0, *hd, ch.data, 0, *cd, _grad_of(grads, blk.conv2.weight), 9, B, hid, hid, H, W,
-                                   nc, f=c1, x_sl=hsl, y_sl=csl, **fr)
+                                   nc, x_sl=hsl, y_sl=csl, **wf(c1, b_c1))
             if split:
-                conv_tangent(ch.data, 0, *cd, blk.conv2.weight, 9, u.data, *cd, B, hid, hid, H, W, nc, fo=relu_bits(c1),
+                conv_tangent(ch.data, 0, *cd, blk.conv2.weight, 9, u.data, *cd, B, hid, hid, H, W, nc, fo=b_c1,
                              transpose=True, x_sl=csl, y_sl=csl)
             else:
                 conv_tangent(ch.data, 0, *cd, blk.conv2.weight, 9, u.data, *cd, B, hid, hid, H, W, nc, fo=c1, **fa, **f32)
             if train:
                 conv_tangent_wgrad(hs[k].data, 0, *hd, u.data, 0, *cd, _grad_of(grads, blk.conv1.weight), 9, B, hid, hid, H, W,
-                                   nc, f=a_in, x_sl=hsl, y_sl=csl, **fr)
+                                   nc, x_sl=hsl, y_sl=csl, **wf(a_in, b_in))
             if split:
                 # the skip connection IN PLACE: c_h += relu'(a_in) . conv1^T(c_u) -- the kernel starts its accumulators from c_h and
                 # the lanes the mask switches off do not store (a separate accumulate pass cost 17 ms of a 235 ms step)
-                conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch.data, *cd, B, hid, hid, H, W, nc, fo=relu_bits(a_in),
+                conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch.data, *cd, B, hid, hid, H, W, nc, fo=b_in,
                              transpose=True, x_sl=csl, y_sl=csl, res_t=ch.data)
             else:
                 conv_tangent(u.data, 0, *cd, blk.conv1.weight, 9, ch2.data, *cd, B, hid, hid, H, W, nc, res_t=ch.data,

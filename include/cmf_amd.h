@@ -122,8 +122,9 @@ long long cmf_conv_tangent_wgrad_ws(const cmf_conv_tangent_args* a);
 int cmf_conv_tangent_wgrad(const cmf_conv_tangent_args* a, const float* gy, float* dw, float* ws, long long ws_bytes,
                            void* stream);
 /* Split-precision variant (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulation, like cmf_conv_tangent_bf16x3) for taps == 9,
- * cin % 64 == 0, cout % 64 == 0, nc % 32 == 0, fmode CMF_F_NONE, CMF_F_RELU (float factor tensor, f_group <= 1) or CMF_F_SELF_RELU; anything else:
- * CMF_EINVAL, use cmf_conv_tangent_wgrad.  Same arguments and workspace.                                                 */
+ * cin % 64 == 0, cout % 64 == 0, nc % 32 == 0, fmode CMF_F_NONE, CMF_F_RELU (float factor tensor, f_group <= 1), CMF_F_RELU_BITS (f = the
+ * relu' bit mask of cmf_conv_tangent_bf16x3's input factor: byte np*f_np + px*(cin/8) + ci/8, f_np in bytes) or CMF_F_SELF_RELU;
+ * anything else: CMF_EINVAL, use cmf_conv_tangent_wgrad.  Same arguments and workspace.                                      */
 int cmf_conv_tangent_wgrad_bf16x3(const cmf_conv_tangent_args* a, const float* gy, float* dw, float* ws, long long ws_bytes,
                                   void* stream);
 

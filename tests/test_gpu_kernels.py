@@ -69,15 +69,17 @@ def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, monke
     # thin shapes (conv_wgrad_thin_kernel): n = ci * 9 + tap in 2 / 4 tiles, a padded output tile, three input blocks of a thin 1x1
     (3, 64, 8, 8, 9, 16), (6, 64, 8, 8, 9, 32), (7, 24, 5, 6, 9, 16), (130, 12, 3, 9, 1, 16),
 ])
-@pytest.mark.parametrize("fmode", ["none", "relu", "tanh", "self"])
+@pytest.mark.parametrize("fmode", ["none", "relu", "tanh", "self", "bits"])
 @pytest.mark.parametrize("layout", ["panel", "slice"])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_conv_tangent_weight_gradient(cin, cout, H, W, taps, nc, fmode, layout, precision):
     """dW of  <gy, conv(F x)>  against torch.autograd in float64; accumulates into an existing gradient.  bf16x3 = the
     split-precision kernel with operands shared through LDS (whole 64-channel blocks, column pairs, factor none / relu)."""
     from cmf_amd import engine as E
-    if precision == "bf16x3" and not (taps == 9 and cin % 64 == 0 and cout % 64 == 0 and nc % 32 == 0 and fmode in ("none", "relu", "self")):
+    if precision == "bf16x3" and not (taps == 9 and cin % 64 == 0 and cout % 64 == 0 and nc % 32 == 0 and fmode in ("none", "relu", "self", "bits")):
         pytest.skip("not covered by the split-precision weight-gradient kernel (the engine uses the fp32 one)")
+    if fmode == "bits" and precision == "f32":
+        pytest.skip("relu' bit masks are read by the split-precision kernel only")
     if layout == "slice" and cin not in (64, 2, 128, 17, 6):
         pytest.skip("slice-major layout: a subset of the shapes is enough")
     gen = torch.Generator().manual_seed(cin * 1000 + cout + H)
@@ -86,8 +88,8 @@ def test_conv_tangent_weight_gradient(cin, cout, H, W, taps, nc, fmode, layout, 
     gy = torch.randn(B, cout, H, W, nc, generator=gen)
     prim = torch.randn(B, cin, H, W, generator=gen)
     fac = {"none": torch.ones_like(prim), "relu": (prim > 0).float(), "tanh": 1 - torch.tanh(prim) ** 2,
-           "self": torch.ones_like(prim)}[fmode]
-    src = {"none": None, "relu": prim, "tanh": torch.tanh(prim), "self": None}[fmode]
+           "self": torch.ones_like(prim), "bits": (prim > 0).float()}[fmode]
+    src = {"none": None, "relu": prim, "tanh": torch.tanh(prim), "self": None, "bits": None}[fmode]
     w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
     xe = torch.relu(x) if fmode == "self" else x                   # SELF_RELU: the input's own relu (primal data in the column slots)
     xin = (xe * fac.unsqueeze(-1)).permute(0, 4, 1, 2, 3).reshape(B * nc, cin, H, W).double()
@@ -105,9 +107,9 @@ def test_conv_tangent_weight_gradient(cin, cout, H, W, taps, nc, fmode, layout, 
     prev = torch.randn(cout, cin, k, k, generator=gen)
     dw = prev.clone().cuda()
     E.conv_tangent_wgrad(to_dev(x), 0, *st(cin), to_dev(gy), 0, *st(cout), dw, taps, B, cin, cout, H, W, nc,
-                         fmode={"none": E.F_NONE, "relu": E.F_RELU, "tanh": E.F_TANH, "self": E.F_SELF_RELU}[fmode],
-                         f=None if src is None else src.cuda(), f_np=cin * HW, f_ci=HW, f_px=1, x_sl=sl(cin), y_sl=sl(cout),
-                         precision=precision)
+                         fmode={"none": E.F_NONE, "relu": E.F_RELU, "tanh": E.F_TANH, "self": E.F_SELF_RELU, "bits": E.F_NONE}[fmode],
+                         f=E.relu_bits(prim.cuda()) if fmode == "bits" else None if src is None else src.cuda(),
+                         f_np=cin * HW, f_ci=HW, f_px=1, x_sl=sl(cin), y_sl=sl(cout), precision=precision)
     assert rel(dw.cpu() - prev, w.grad) < (2e-5 if precision == "f32" else 5e-5)
 
 

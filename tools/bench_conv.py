@@ -25,12 +25,13 @@ x = torch.randn(B, ch, H, H, nc, device="cuda"); prim = torch.randn(B, ch, H, H,
 res = torch.randn(B, ch, H, H, nc, device="cuda") if args.res else None
 y = torch.randn(B, ch, H, H, nc, device="cuda") if args.wgrad else torch.empty(B, ch, H, H, nc, device="cuda")
 w = torch.nn.Parameter(torch.randn(ch, ch, 3, 3, device="cuda") / 24)
-fm = {"relu": E.F_RELU, "none": E.F_NONE}[args.fmode]
+fm = {"relu": E.F_RELU, "none": E.F_NONE, "bits": E.F_RELU}[args.fmode]
+wg_f = E.relu_bits(prim) if args.fmode == "bits" else prim      # --wgrad: relu' as a bit mask instead of the float activation
 st = (ch * HW * nc, 16, ch * nc) if args.layout == "slice" else (ch * HW * nc, HW * nc, nc)
 sl = ch * 16 if args.layout == "slice" else 16
 dw = torch.zeros(ch, ch, 3, 3, device="cuda")
 def run_wgrad():
-    E.conv_tangent_wgrad(x, 0, *st, y, 0, *st, dw, 9, B, ch, ch, H, H, nc, fmode=fm, f=prim if fm else None, f_np=ch * HW, f_ci=HW,
+    E.conv_tangent_wgrad(x, 0, *st, y, 0, *st, dw, 9, B, ch, ch, H, H, nc, fmode=fm, f=wg_f if fm else None, f_np=ch * HW, f_ci=HW,
                          f_px=1, x_sl=sl, y_sl=sl)
 def run():
     if args.wgrad:
