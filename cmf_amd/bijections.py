@@ -177,7 +177,7 @@ class AffineCouplingBijection(Bijection):
             return ctx
         view, maps = self.view(z.device), self.maps(z.device)
         zb = z.clone()
-        y, g, acts = E.net_primal(self.net, z, view, need_acts=True)
+        y, g, acts = E.net_primal(self.net, z, view, need_acts=E.train_acts_mode(self.net, view, z.shape[0], T))
         saved = V = YT = None
         if T is not None:
             saved = []
@@ -219,7 +219,7 @@ class AffineCouplingBijection(Bijection):
         """``encode_`` keeping the layer input, the network output and its activations for ``encode_backward_``."""
         view = self.view(z.device)
         xb = z.clone()
-        y, g, acts = E.net_primal(self.net, z, view, need_acts=True)
+        y, g, acts = E.net_primal(self.net, z, view, need_acts=E.train_acts_mode(self.net, view, z.shape[0]))
         E.acl_primal(z, y, self.maps(z.device), decode=False, lj=lj)
         return xb, y, g, acts
 

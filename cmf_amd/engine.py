@@ -825,6 +825,7 @@ def net_primal(net, z, view, need_acts=True):
                     B, view.cin, hid, H, W, imode=F_RAW if view.mask is not None else F_NONE, mask=view.mask, f_c=HW, f_px=1)
         if B % 16 == 0 and _shape_ok_bf16x3(9, hid, W, False, H, hid):
             return _resnet_primal_grouped(net, blocks, convf, a, B, hid, cout, H, W, need_acts)
+        need_acts = True if need_acts == "train" else need_acts
         acts = [a]
         for blk in blocks:
             c1 = new(hid)
@@ -870,6 +871,29 @@ class BitMask:
         self.np_bytes = HW * (C // 8)
 
 
+class ActList(list):
+    """Activations of a ResNet coupler kept for TRAINING: the elements are what the tangent pass and the reverse sweep read (the
+    float a_0, relu' BitMasks of the hidden activations, the last activation as floats -- the "bits" form), and ``grouped`` holds
+    ALL of them as the sample-grouped float tensors (B/16, C, HW, 16) the primal pass produced, which is what
+    ``net_primal_backward`` reads.  (Before: 17 activations per coupler regrouped to the per-sample layout after the forward pass
+    and back again in the backward pass -- 850 launches per training step.)"""
+    grouped = None
+
+
+def train_acts_mode(net, view, B, T=None):
+    """``need_acts`` for a training forward: "train" (ActList) where every consumer can work from bit masks and grouped floats,
+    else True (per-sample float activations)."""
+    if net.kind != "resnet" or B % 32 or PRIMAL_PRECISION != "f32":
+        return True
+    conv0 = _resnet_parts(net)[0]
+    hid, H, W = conv0.out_channels, view.geom.H, view.geom.W
+    if hid % 64 or not _shape_ok_bf16x3(9, hid, W, True, H, hid):
+        return True
+    if T is not None and (TANGENT_PRECISION != "bf16x3" or T.nc % 32):
+        return True
+    return "train"
+
+
 def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts):
     """Hidden 3x3 convs of the primal ResNet through the TANGENT conv kernels: the 16 column slots carry 16 samples (relu
     applied elementwise on load, bias as per-channel constant); ``PRIMAL_PRECISION`` picks the kernel.
@@ -879,7 +903,8 @@ def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts
     HW, G, dev = H * W, B // 16, a0.device
     pn = (hid * HW * 16, HW * 16, 16)                       # (np, chan, px) strides of a grouped tensor
     new = lambda: torch.empty(G * hid * HW * 16, dtype=torch.float32, device=dev)
-    bits = need_acts == "bits" and PRIMAL_PRECISION == "f32" and hid % 16 == 0
+    train = need_acts == "train"                          # ActList: the "bits" form + the grouped floats
+    bits = (need_acts == "bits" or train) and PRIMAL_PRECISION == "f32" and hid % 16 == 0
     a = primal_regroup(a0, True)
     acts, masks = [a], []
     for blk in blocks:
@@ -904,6 +929,10 @@ def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts
     if not need_acts:
         return y, g, None
     std_of = lambda t: primal_regroup(t.view(G, -1), False).view(B, hid, H, W)
+    if train:
+        out = ActList([a0] + masks[:-1] + [std_of(acts[-1])] if bits else [a0] + [std_of(t) for t in acts[1:]])
+        out.grouped = acts
+        return y, g, out
     if bits:
         return y, g, [a0] + masks[:-1] + [std_of(acts[-1])]
     # The tangent pass reads relu' per (channel, pixel) of ONE sample: from the grouped layout every such read is its
@@ -1035,7 +1064,9 @@ def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None, cross=None):
             #   c_u = relu'(c1) . conv2^T(c_h2);   c_h = c_h2 + relu'(a_in) . conv1^T(c_u)
             # split kernels: relu' of both activations as bit masks, shared by the weight gradients (input factor) and the
             # transposed convs (output mask)
-            b_c1, b_in = (relu_bits(c1), relu_bits(a_in)) if split else (None, None)
+            bits_of = lambda t: t if isinstance(t, BitMask) else relu_bits(t)      # ActList: written by the primal pass
+            b_c1, b_in = (bits_of(c1), bits_of(a_in)) if split else (None, None)
+            assert split or not isinstance(c1, BitMask), "bit-mask activations need the split-precision reverse sweep"
             wf = lambda act, bits: dict(f=bits) if split and nc % 32 == 0 else dict(f=act, **fr)   # (the fp32 kernel reads floats)
             if train:
                 conv_tangent_wgrad(us[k].data, 0, *hd, ch.data, 0, *cd, _grad_of(grads, blk.conv2.weight), 9, B, hid, hid, H, W,
@@ -1138,7 +1169,9 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
     tr = dict(transpose=True, precision="f32")
     self_fo = lambda t: dict(fo=t, fo_np=hid * HW * 16, fo_co=HW * 16, fo_px=16, fomode=F_SELF_RELU)
     du = stanh_backward(dy, dg, y, g, net.weights, net.bias, _grad_of(grads, net.weights).view(-1), _grad_of(grads, net.bias).view(-1))
-    du_g, a_g = grp(du), grp(acts[-1])
+    kept = getattr(acts, "grouped", None) if Bp == B else None   # ActList: the forward pass's grouped tensors, no regrouping
+    gact = lambda i: kept[i] if kept is not None else grp(acts[i])
+    du_g, a_g = grp(du), gact(len(acts) - 1)
     # u = convf(relu(a_K)) + bf
     conv_tangent_wgrad(a_g, 0, *pn(hid), du_g, 0, *pn(cout), _grad_of(grads, convf.weight), 1, G, hid, cout, H, W, 16, fmode=F_SELF_RELU)
     channel_sum(du_g, *pn(cout), G, cout, HW, 16, _grad_of(grads, convf.bias))
@@ -1146,7 +1179,7 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
     conv_tangent(du_g, 0, *pn(cout), convf.weight, 1, da, *pn(hid), G, cout, hid, H, W, 16, **self_fo(a_g), **tr)
     for k in reversed(range(len(blocks))):
         blk = blocks[k]
-        a_in, c1 = grp(acts[2 * k]), grp(acts[2 * k + 1])
+        a_in, c1 = gact(2 * k), gact(2 * k + 1)
         # a' = a + conv2(relu(c1)) + b2,  c1 = conv1(relu(a)) + b1
         hidden_wgrad(c1, da, blk.conv2.weight)
         channel_sum(da, *pn(hid), G, hid, HW, 16, _grad_of(grads, blk.conv2.bias))

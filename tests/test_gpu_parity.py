@@ -751,6 +751,32 @@ def test_recomputation_per_coupling_layer_gives_the_same_gradients(name):
         assert rel(grads_b[p], grads_a[p]) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["c3_mnist_full"])           # 64-channel couplers: the small fixtures' networks do not qualify
+def test_training_from_grouped_activations_and_bit_masks_gives_the_same_gradients(name, monkeypatch):
+    """Batches of a multiple of 32 samples train from ``engine.ActList``: relu' bit masks written by the primal pass and the
+    sample-grouped float activations, instead of 17 per-sample float activations per coupler regrouped forth and back.  Same
+    kernels' arithmetic on the same data, so: identical loss, gradients equal to rounding (the weight gradients read the masks
+    as bits instead of as floats, the forward tangent pass runs the bit-mask variant of the split kernel)."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    x0 = g["head_input"].float() if "head_input" in g else g["x"].float()
+    gen = torch.Generator().manual_seed(5)
+    x = x0[torch.randint(0, x0.shape[0], (32,), generator=gen)].cuda()
+    x = x + 0.01 * torch.randn(x.shape, generator=gen).cuda()            # 32 distinct samples around the fixture's inputs
+    kw = dict(add_offdiagonal_metric_reg=True)
+    modes = []
+    real = E.train_acts_mode
+    monkeypatch.setattr(E, "train_acts_mode", lambda *a, **k: modes.append(real(*a, **k)) or modes[-1])
+    loss_a, elbo_a, grads_a = head.loss_and_gradients(x.clone(), **kw)
+    assert "train" in modes, "the batch of 32 did not take the ActList path"
+    monkeypatch.setattr(E, "train_acts_mode", lambda *a, **k: True)
+    loss_b, elbo_b, grads_b = head.loss_and_gradients(x.clone(), **kw)
+    assert rel(elbo_a, elbo_b) < 1e-6 and set(grads_a) == set(grads_b)
+    for p in grads_a:
+        assert rel(grads_a[p], grads_b[p]) < 2e-6
+
+
 def test_encode_layers_backward_full_size():
     """Every coupling layer of the full-size MNIST model's ENCODE chain, on the float64 oracle's own layer inputs (so no relu
     mask can differ): ``encode_train_`` / ``encode_backward_`` -- coupling backward, ScaledTanh stage, primal backward of the
