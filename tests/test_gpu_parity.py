@@ -770,6 +770,12 @@ def test_training_from_grouped_activations_and_bit_masks_gives_the_same_gradient
     monkeypatch.setattr(E, "train_acts_mode", lambda *a, **k: modes.append(real(*a, **k)) or modes[-1])
     loss_a, elbo_a, grads_a = head.loss_and_gradients(x.clone(), **kw)
     assert "train" in modes, "the batch of 32 did not take the ActList path"
+    head.recompute = True                                # ... and with recomputation per coupling layer on the same path
+    loss_r, elbo_r, grads_r = head.loss_and_gradients(x.clone(), **kw)
+    head.recompute = None
+    assert torch.equal(elbo_a, elbo_r)
+    for p in grads_a:
+        assert rel(grads_r[p], grads_a[p]) < 1e-6
     monkeypatch.setattr(E, "train_acts_mode", lambda *a, **k: True)
     loss_b, elbo_b, grads_b = head.loss_and_gradients(x.clone(), **kw)
     assert rel(elbo_a, elbo_b) < 1e-6 and set(grads_a) == set(grads_b)
