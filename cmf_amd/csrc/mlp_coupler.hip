@@ -71,17 +71,19 @@ __global__ void pack_mlp_layer_kernel(const float* __restrict__ w, const float* 
 }
 
 // LDS-DMA copy of `nfloat` floats (a multiple of 4) global -> LDS by the whole workgroup, lane-linear
+template <int NW = WAVES>
 __device__ __forceinline__ void stage_image(const float* __restrict__ src, float* dst, long long nfloat, int tid) {
   const long long nchunk = nfloat >> 2;                 // 16-byte chunks
-  for (long long c0 = 0; c0 < nchunk; c0 += WAVES * 64) {
+  for (long long c0 = 0; c0 < nchunk; c0 += NW * 64) {
     const long long c = c0 + tid;                       // wave-instruction: 64 consecutive chunks = 1 KiB
     if (c < nchunk)                                     // destination = wave-uniform base (+ lane x 16 B by the hardware)
       __builtin_amdgcn_global_load_lds(src + 4 * c, dst + 4 * (c - (tid & 63)), 16, 0, 0);
   }
 }
 
-template <int HT, bool TAN>
-__global__ __launch_bounds__(WAVES * 64) void mlp_coupler_kernel(cmf_mlp_coupler_args a, int n_tiles, int buf_floats, int scr_floats) {
+// NW waves per workgroup: 8, or 4 where 8-wave tiles would leave CUs without work (launcher)
+template <int HT, bool TAN, int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_coupler_kernel(cmf_mlp_coupler_args a, int n_tiles, int buf_floats, int scr_floats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,9 +98,9 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_coupler_kernel(cmf_mlp_coupler
   const bool is_primal = !TAN || jc == a.ncols;
 
   int gcount = 0;                                        // layers staged so far: buffer parity
-  if ((int)blockIdx.x < n_tiles) stage_image(a.w + a.w_off[0], smem, image_floats(layer_kg(a, 0, HT), layer_mt(a, 0, HT)), tid);
+  if ((int)blockIdx.x < n_tiles) stage_image<NW>(a.w + a.w_off[0], smem, image_floats(layer_kg(a, 0, HT), layer_mt(a, 0, HT)), tid);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int b0 = (tile * WAVES + wave) * spt;
+    const int b0 = (tile * NW + wave) * spt;
     const bool live = b0 < a.B;                          // wave-uniform
     const int bmine = b0 + ks;                           // this lane's sample
     const bool colok = slot_ok && bmine < a.B;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlp_coupler_kernel(cmf_mlp_coupler
       {
         const int nl = l + 1 < L ? l + 1 : 0;
         if (l + 1 < L || tile + (int)gridDim.x < n_tiles)
-          stage_image(a.w + a.w_off[nl], smem + ((gcount + 1) & 1) * buf_floats,
+          stage_image<NW>(a.w + a.w_off[nl], smem + ((gcount + 1) & 1) * buf_floats,
                       image_floats(layer_kg(a, nl, HT), layer_mt(a, nl, HT)), tid);
       }
       if (!live) continue;
@@ -364,23 +366,29 @@ int launch_split(const cmf_mlp_coupler_args& a, int buf_floats, hipStream_t s) {
   return 0;
 }
 
-template <int HT, bool TAN>
+template <int HT, bool TAN, int NW = WAVES>
 int launch(const cmf_mlp_coupler_args& a, int buf_floats, hipStream_t s) {
   const int spt = TAN ? 16 / (a.ncols + 1) : 16;
-  const int per_tile = WAVES * spt;
+  const int per_tile = NW * spt;
   const int n_tiles = cmf_ceil_div(a.B, per_tile);
+  if constexpr (TAN && NW == 8) {
+    // TANGENT mode with several samples per wave tile (small d): 8-wave tiles leave CUs without a workgroup (C2a, d = 2,
+    // B = 4096: 103 tiles of 40 samples on 256 CUs, two waves per SIMD on those) -- 4-wave workgroups put one wave on every SIMD of
+    // twice as many CUs
+    if (n_tiles < cmf_device_cus() && a.B > 4 * spt) return launch<HT, TAN, 4>(a, buf_floats, s);
+  }
   const int out_pad = (a.width[a.n_layers] + 15) / 16 * 16;
   const int s_floats = TAN ? 128 * spt : 0;              // S [sample slot][128] and the output table Y share the region
   const int scr_floats = 16 * out_pad > s_floats ? 16 * out_pad : s_floats;
-  const int lds = (2 * buf_floats + WAVES * scr_floats) * (int)sizeof(float);
+  const int lds = (2 * buf_floats + NW * scr_floats) * (int)sizeof(float);
   if (lds > 160 * 1024) return CMF_ERANGE;
-  auto k = mlp_coupler_kernel<HT, TAN>;
+  auto k = mlp_coupler_kernel<HT, TAN, NW>;
   if (hipError_t e = cmf_set_dynamic_lds((const void*)k, lds); e != hipSuccess) return (int)e;
   const int cus = cmf_device_cus();
   // small images leave room for more than one workgroup per CU; the grid is persistent over the tiles
   const int per_cu = lds <= 40 * 1024 ? 2 : 1;
   const int grid = n_tiles < cus * per_cu ? n_tiles : cus * per_cu;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(WAVES * 64), lds, s, a, n_tiles, buf_floats, scr_floats);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, s, a, n_tiles, buf_floats, scr_floats);
   CMF_LAUNCH_CHECK();
   return 0;
 }
