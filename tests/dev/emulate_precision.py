@@ -3,7 +3,11 @@
 oracle on the full-size MNIST model (fixture c3_mnist_full, B = 2, d = 64) and compare log-det / likelihood / g_ij / J with
 an fp64 evaluation.  This is how the bf16x3 scheme of conv_tangent_bf16x3.hip was chosen.
 
-  python tests/dev/emulate_precision.py [scheme ...]      schemes: f32 bf16x1 bf16x2 bf16x3 f16x1 f16x2 f16x3
+  python tests/dev/emulate_precision.py [scheme ...]      schemes: f32 bf16x1 bf16x2 bf16x3 f16x1 f16x2 f16x3 wino_f32 wino_bf16x3
+
+wino_*: the same convolutions as Winograd F(2x2, 3x3) -- input and weight transforms in fp32, the sixteen channel contractions
+in fp32 or as bf16x3 split products, output transform in fp32: 2.25x fewer multiplications (a next-round lever: both split
+kernels sit at the power limit of the matrix pipes); this measures what it would cost in accuracy.
 """
 import os, sys, time
 import torch
@@ -24,9 +28,38 @@ def split(t, dt, n):
     return parts
 
 
+_G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]])
+_BT = torch.tensor([[1., 0., -1., 0.], [0., 1., 1., 0.], [0., -1., 1., 0.], [0., 1., 0., -1.]])
+_AT = torch.tensor([[1., 1., 1., 0.], [0., 1., -1., -1.]])
+
+
+def winograd_conv(x, w, nsplit):
+    """3x3, padding 1, even H and W: y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A per 4x4 input tile (stride 2)."""
+    N, C, H, W = x.shape
+    G, BT, AT = _G.to(x.dtype), _BT.to(x.dtype), _AT.to(x.dtype)
+    U = torch.einsum("ij,ocjk,lk->ocil", G, w, G)                                   # (co, ci, 4, 4)
+    d = F.pad(x, (1, 1, 1, 1)).unfold(2, 4, 2).unfold(3, 4, 2)                     # (N, C, H/2, W/2, 4, 4)
+    V = torch.einsum("ij,nctujk,lk->nctuil", BT, d, BT)
+    if nsplit:
+        dt = torch.bfloat16
+        Vs, Us = split(V, dt, 2), split(U, dt, 2)
+        M = torch.einsum("ocil,nctuil->notuil", Us[0], Vs[0]) + torch.einsum("ocil,nctuil->notuil", Us[0], Vs[1]) \
+            + torch.einsum("ocil,nctuil->notuil", Us[1], Vs[0])
+    else:
+        M = torch.einsum("ocil,nctuil->notuil", U, V)
+    Y = torch.einsum("ij,notujk,lk->notuil", AT, M, AT)                            # (N, co, H/2, W/2, 2, 2)
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(N, w.shape[0], H, W)
+
+
 def make_conv(scheme):
     if scheme == "f32":
         return real_conv2d
+    if scheme.startswith("wino"):
+        def wconv(x, w, b=None, **kw):
+            if b is not None or w.shape[1] % 32 or w.shape[-1] != 3 or x.dtype != torch.float32 or x.shape[-1] % 2 or x.shape[-2] % 2:
+                return real_conv2d(x, w, b, **kw)
+            return winograd_conv(x, w, scheme.endswith("bf16x3"))
+        return wconv
     dt = torch.bfloat16 if scheme.startswith("bf16") else torch.float16
     n = int(scheme[-1])
 
