@@ -6,7 +6,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats -- python3 bench.py --train --batch 64 --steps 2 --warmup 1 > $out/stats.log 2>&1 || { tail -5 $out/stats.log; exit 1; }
-python3 tools/rocprof_stats.py $out/stats $out/kernel_stats.csv > /dev/null 2>&1
+python3 tools/rocprof_stats.py $out/stats $out/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python3 bench.py --train --batch 64 --steps 2 --warmup 1  (MI355X, C3 model, 64 samples; 3 training steps in the trace; durations in us; tools/gpu_profile_train.sh)" > /dev/null 2>&1
 rm -rf $out/stats
 python3 - $out/kernel_stats.csv <<'PY'
 import csv, sys
