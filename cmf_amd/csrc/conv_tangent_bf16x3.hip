@@ -793,8 +793,10 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 }
 
 // weight pre-split / pre-arrangement: out[cog][chunk][hl][s][cot 4][kq][co 16][8] bf16
+// transpose: `w` is the LAYER's weight [cin][cout][3][3] and the pack is of its adjoint operator -- channels swapped, taps
+// flipped -- [cout][cin][tap] = w[ci][co][8 - tap]
 __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cout,
-                                          int cin, long long total) {
+                                          int cin, long long total, int transpose) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int j = (int)(i & 7), col = (int)((i >> 3) & 15), kq = (int)((i >> 7) & 3), cot = (int)((i >> 9) & 3);
@@ -814,7 +816,7 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned 
     ci = (ch - 3 + kq) * 8 + j;
   }
   float v = 0.f;
-  if (co < cout && tap < 9) v = w[((long long)co * cin + ci) * 9 + tap];
+  if (co < cout && tap < 9) v = transpose ? w[((long long)ci * cout + co) * 9 + (8 - tap)] : w[((long long)co * cin + ci) * 9 + tap];
   const __bf16 h = (__bf16)v;
   const float hf = (float)h;
   const __bf16 r = hl ? (__bf16)(v - hf) : h;
@@ -858,14 +860,18 @@ inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 29); }   // ele
 
 }  // namespace
 
+extern "C" int cmf_pack_weight_bf16x3_t(const float* w, void* out, int cout, int cin, int transpose, long long* out_bytes, void* stream);
 extern "C" int cmf_pack_weight_bf16x3(const float* w, void* out, int cout, int cin, long long* out_bytes, void* stream) {
+  return cmf_pack_weight_bf16x3_t(w, out, cout, cin, 0, out_bytes, stream);
+}
+extern "C" int cmf_pack_weight_bf16x3_t(const float* w, void* out, int cout, int cin, int transpose, long long* out_bytes, void* stream) {
   if (cout <= 0 || cin <= 0 || cin % 8) return CMF_EINVAL;
   const long long total = (long long)((cout + 63) / 64) * (cin / 8) * 2 * 3 * 4 * 4 * 16 * 8;   // bf16 elements
   if (out_bytes) *out_bytes = total * 2;
   if (!out) return 0;
   if (!w) return CMF_EINVAL;
   hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     w, (unsigned short*)out, cout, cin, total);
+                     w, (unsigned short*)out, cout, cin, total, transpose ? 1 : 0);
   CMF_LAUNCH_CHECK();
   return 0;
 }

@@ -179,16 +179,19 @@ class _PackCache:
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
         n = C.c_longlong(0)
         w = weight.detach().contiguous()
+        # a stale entry's buffer is reused when the size still fits (training: every pack is rebuilt after every optimiser step)
+        old = hit[2] if hit is not None and hit[0]() is weight and hit[2].device == weight.device else None
+        buf = lambda nbytes, dt: old if old is not None and old.dtype == dt and old.numel() * old.element_size() == nbytes \
+            else torch.empty(nbytes // torch.empty(0, dtype=dt).element_size(), dtype=dt, device=weight.device)
         if bf16x3:
-            if transpose:                                  # the adjoint operator: channels swapped, taps flipped (tiny, once per version)
-                w = w.transpose(0, 1).flip(2, 3).contiguous()
+            if transpose:                                  # the adjoint operator: channels swapped, taps flipped -- by the pack kernel
                 cout, cin = cin, cout
-            _lib.check(lib.cmf_pack_weight_bf16x3(None, None, cout, cin, C.byref(n), None), "pack size")
-            out = torch.empty(n.value, dtype=torch.uint8, device=weight.device)
-            _lib.check(lib.cmf_pack_weight_bf16x3(_p(w), _p(out), cout, cin, None, _stream()), "cmf_pack_weight_bf16x3")
+            _lib.check(lib.cmf_pack_weight_bf16x3_t(None, None, cout, cin, int(transpose), C.byref(n), None), "pack size")
+            out = buf(n.value, torch.uint8)
+            _lib.check(lib.cmf_pack_weight_bf16x3_t(_p(w), _p(out), cout, cin, int(transpose), None, _stream()), "cmf_pack_weight_bf16x3_t")
         else:
             _lib.check(lib.cmf_pack_weight(None, None, cout, cin, taps, int(transpose), C.byref(n), None), "pack size")
-            out = torch.empty(n.value, dtype=torch.float32, device=weight.device)
+            out = buf(4 * n.value, torch.float32)
             _lib.check(lib.cmf_pack_weight(_p(w), _p(out), cout, cin, taps, int(transpose), None, _stream()), "cmf_pack_weight")
         if len(self._store) > 4096:                                   # drop entries whose parameter is gone
             self._store = {k: v for k, v in self._store.items() if v[0]() is not None}

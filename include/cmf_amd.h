@@ -109,6 +109,9 @@ int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
  * the reverse sweep.  A residual is accepted together with that bit mask only IN PLACE (r == y with y's strides, no bias):  y <- y + Fo . conv(x)  -- the skip connection of the reverse sweep; entries the mask switches off are not written at all
  * (they keep their bits).  mask_out is not supported. */
 int cmf_pack_weight_bf16x3(const float* w, void* out, int cout, int cin, long long* out_bytes, void* stream);
+/* the same pack of the ADJOINT operator straight from the layer's weight: transpose != 0 reads w as [cin][cout][3][3] and packs
+ * [cout][cin][tap] = w[ci][co][8 - tap] (channels swapped, taps flipped: cmf_pack_weight's transpose for the split kernel) */
+int cmf_pack_weight_bf16x3_t(const float* w, void* out, int cout, int cin, int transpose, long long* out_bytes, void* stream);
 int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* a, void* stream);
 
 /* Weight gradient of the tangent convolution (training; the reference gets it from autograd through
