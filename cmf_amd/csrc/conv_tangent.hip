@@ -387,6 +387,12 @@ extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
     return CMF_ERANGE;
   hipStream_t s = (hipStream_t)stream;
   const bool seven = (a.taps == 9) ? (a.W % 14 == 0) : (HW % 28 == 0 && HW % 32 != 0);
+  if (a.taps == 9 && !seven && a.W % 8 == 0 && a.cout % 64 == 0) {
+    // tiny grids on 8-multiple widths (the primal pass of a 32-sample CIFAR shard: 32 tile items): 2 x 8 tiles instead of 2 x 16 --
+    // twice the workgroups, half the serial MFMA work in each: the launch is one item's latency
+    const long long items8 = (long long)cmf_ceil_div(a.W, 16) * cmf_ceil_div(a.H, 2) * (a.nc / 16) * (a.cout / 64) * a.np;
+    if (items8 * 4 <= 128) return launch_cot<9, 4>(a, s);
+  }
   if (a.taps == 9) return seven ? launch_cot<9, 7>(a, s) : launch_cot<9, 8>(a, s);
   return seven ? launch_cot<1, 7>(a, s) : launch_cot<1, 8>(a, s);
 }
