@@ -70,9 +70,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-batch", type=int, default=None, help="CPU baseline sample size (0 disables); C3: 32 = ~12 s on 16 cores")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-f32-exact", action="store_true", help="skip the exact-fp32 leg of the default C3 run")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (default for the launch-bound "
-                                                          "c1 / c2a / c2b); the roofline leg then comes from separate eager steps")
-    ap.add_argument("--no-graph", action="store_true", help="c1 / c2a / c2b: time eager launches instead of graph replays")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (the default for evaluation "
+                                                          "steps); the roofline leg then comes from separate eager steps")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of graph replays (the dominant kernel's HIP "
+                                                             "events then sit inside the timed region)")
     ap.add_argument("--hutchinson", action="store_true", help="c5: train-mode stochastic log-det (Hutchinson S=4 + CG) instead of the "
                                                                "exact eval path")
     ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
@@ -83,11 +84,18 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 "
                                                        "on a one-GPU box together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (never a measurement)")
+    ap.add_argument("--no-legs", action="store_true", help="default C3 run only: skip the secondary measurements (N = 1: c5, c2b, "
+                                                            "c5_train, train; N > 1: strong_c3, c5)")
+    ap.add_argument("--leg-steps", type=int, default=3, help="timed steps of each secondary measurement")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="--gpus N from a bare shell: seconds before the parent "
+                                                                          "stops every rank and returns 124")
     ap.add_argument("--train", action="store_true",
                     help="SECONDARY metric (SURVEY 8d): time training steps instead -- forward + loss.backward() on the HIP kernels + "
                          "data-parallel gradient all-reduce + fused Adam; use --batch 64 (the reference's per-GPU shard)")
     args = ap.parse_args(argv)
-    if args.config in ("c1", "c2a", "c2b") and not args.no_graph and not args.train:
+    if not args.no_graph and not args.train and not args.hutchinson:
+        # every evaluation step replays a captured HIP graph (round 3: C3 / C5 too -- a C3 step is ~1500 launches, a C5 shard is
+        # launch-bound outright); the per-kernel events of the roofline then come from eager steps right after the timed region
         args.graph = True
     if args.steps is None:
         args.steps = 20 if args.config in ("c1", "c2a", "c2b") else 3
@@ -103,26 +111,57 @@ def parse_args(argv=None):
 # ----------------------------------------------------------------------------------------------------------------------
 
 
-def spawn_ranks(args, argv):
+def spawn_ranks(args, argv, script=None):
+    """Start one fresh process per GPU, relay rank 0's JSON line, return the exit code.  Every child is watched: the first one
+    that exits non-zero (e.g. RCCL could not initialise: run_rank prints the reason and exits 3) stops the others at once --
+    they would otherwise sit in the rendezvous or a collective until the backend's own timeout -- and an overall deadline
+    (--launch-timeout) bounds the whole run.  Nothing is ever re-executed in a process that has touched the GPU."""
+    import threading
     with socket.socket() as s:
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+        port = s.getsockname()[1]                      # released just before the ranks start; a clash shows up as a failed rank
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
         env.setdefault("OMP_NUM_THREADS", "2")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [l for l in (out0 or "").splitlines() if l.strip()]
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(args.launch_timeout)
+    timed_out = False
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes) or any(c not in (None, 0) for c in codes):
+            break
+        if time.monotonic() > deadline:
+            timed_out = True
+            break
+        time.sleep(0.1)
+    for p in procs:                                    # stop whoever is still running (only after a failure or the deadline)
+        if p.poll() is None:
+            p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=15)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    reader.join(timeout=5)
+    codes = [p.returncode for p in procs]
+    lines = [l for l in ("".join(o or "" for o in out0)).splitlines() if l.strip()]
     for l in lines:
         print(l, flush=True)
+    if timed_out:
+        print(f"[bench] ranks still running after --launch-timeout {args.launch_timeout:.0f} s: stopped (codes {codes})", file=sys.stderr)
+        return 124
     if any(codes):
-        print(f"[bench] rank exit codes {codes}", file=sys.stderr)
-        return next(c for c in codes if c) or 1
+        print(f"[bench] rank exit codes {codes} (a failing rank stops the others; its own message is above)", file=sys.stderr)
+        return next(c for c in codes if c and c > 0) if any(c and c > 0 for c in codes) else 1
     if not any(l.lstrip().startswith("{") for l in lines):
         print("[bench] rank 0 printed no JSON line", file=sys.stderr)
         return 1
@@ -203,13 +242,27 @@ def pmc_traffic(precision, B):
     t = j.get("traffic_bytes_per_launch")
     if t is None:
         return None, None
-    return t * B / float(j.get("batch", 512)), (f"committed PMC passes (profiles/{os.path.basename(path)}, B={j.get('batch', 512)}) "
-                                                f"scaled to per_gpu_batch={B}; not collected by this run")
+    # the passes were taken on ONE version of the kernel: say whether it is the source this run was built from
+    measured, current = j.get("kernel_source_sha16"), kernel_source_sha16(precision)
+    same = {True: "same kernel source as this build", False: "STALE: the kernel source has changed since (re-run tools/refresh_profiles.sh)",
+            None: "kernel source version not recorded"}[None if measured is None else measured == current]
+    return t * B / float(j.get("batch", 512)), (f"committed PMC passes (profiles/{os.path.basename(path)}, B={j.get('batch', 512)}, kernel "
+                                                f"source sha16 {measured}: {same}) scaled to per_gpu_batch={B}; not collected by this run")
 
 
-def train_bench(args, density, x, B, rank, world, device, off=True):
+def kernel_source_sha16(precision):
+    """First 16 hex digits of the SHA-256 of the dominant kernel's source file (stamped into the PMC summaries by
+    tools/pmc_kernel.py --source)."""
+    import hashlib
+    src = os.path.join(ROOT, "cmf_amd", "csrc", "conv_tangent_bf16x3.hip" if precision == "bf16x3" else "conv_tangent.hip")
+    with open(src, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def train_leg(steps, warmup, config, density, x, B, rank, world, device, off=True):
     """Secondary metric: training samples / s (one process per GPU, flat gradient all-reduce over RCCL, fused Adam).  C3: the
-    Cholesky objective with the off-diagonal metric term; C5: train mode selects the Hutchinson + CG surrogate (non_square.py:131-138)."""
+    Cholesky objective with the off-diagonal metric term; C5: train mode selects the Hutchinson + CG surrogate
+    (non_square.py:131-138), whose backward runs through the 2 S probe directions.  Returns the result object (rank 0) or None."""
     import torch
     import torch.distributed as dist
     from cmf_amd.optim import FlatOptimizer
@@ -230,31 +283,34 @@ def train_bench(args, density, x, B, rank, world, device, off=True):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    torch.cuda.reset_peak_memory_stats(device)
+    for _ in range(warmup):
         step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     fence()
     dt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": ("training samples/sec (forward + backward + Adam, JtJ-cholesky objective), MNIST D=784 d=64" if args.config == "c3" else
-                       f"training samples/sec (forward + backward + Adam), {METRICS[args.config].split(', ', 1)[1]}"),
-            "value": B * world * args.steps / dt,
-            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (3x3 tangent convs, their transposes and weight gradients as bf16x3 split MFMA, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": ("C3 / C4 model, one optimiser step per batch, g_ij off-diagonal objective" if args.config == "c3" else
-                                    CONFIGS[args.config][4] + ", one optimiser step per batch, train-mode objective"), "per_gpu_batch": B,
-                       "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss),
-                       "peak_memory_gib": torch.cuda.max_memory_allocated(device) / 2 ** 30}}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    density.eval()
+    peak = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    del opt
+    if rank != 0:
+        return None
+    return {
+        "metric": ("training samples/sec (forward + backward + Adam, JtJ-cholesky objective), MNIST D=784 d=64" if config == "c3" else
+                   f"training samples/sec (forward + backward + Adam), {METRICS[config].split(', ', 1)[1]}"),
+        "value": B * world * steps / dt,
+        "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (3x3 tangent convs, their transposes and weight gradients as bf16x3 split MFMA, fp32 accumulate)", "data": "synthetic",
+        "config": {"workload": ("C3 / C4 model, one optimiser step per batch, g_ij off-diagonal objective" if config == "c3" else
+                                CONFIGS[config][4] + ", one optimiser step per batch, train-mode objective (Hutchinson S=4 + CG)"),
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss),
+                   "peak_memory_gib": peak}}
 
 
 def dominant(rows):
@@ -263,7 +319,7 @@ def dominant(rows):
     return (name, *rows[name])
 
 
-def roofline_of(name, n, ms, flops, nbytes, step_ms_total, precision, B):
+def roofline_of(name, n, ms, flops, nbytes, step_ms_total, precision, B, pmc=True):
     """Roofline object for one kernel family from its HIP-event totals."""
     sec = ms * 1e-3
     tf, gbs = flops / sec / 1e12, nbytes / sec / 1e9
@@ -274,7 +330,7 @@ def roofline_of(name, n, ms, flops, nbytes, step_ms_total, precision, B):
         # Split precision: every fp32-grade product is THREE bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the matrix work
         # this algorithm needs is 3x the algorithmic fp32 flops; `achieved` counts exactly that (nothing else: the K packing
         # has no zero-weight padding) against the dense bf16 peak.  `hbm_view` carries the memory side.
-        traffic, note = pmc_traffic("bf16x3", B)
+        traffic, note = pmc_traffic("bf16x3", B) if pmc else (None, "PMC passes were taken on the C3 command only")
         return {"bound": "mfma", "achieved": 3.0 * tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": 3.0 * tf / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": note,
                 "kernel": "conv_tangent_bf16x3_kernel (3x3, 64->64 channels, all d Jacobian columns; split-precision bf16 MFMA, "
@@ -286,12 +342,130 @@ def roofline_of(name, n, ms, flops, nbytes, step_ms_total, precision, B):
                                            "source": "profiles/r02_mfma_sustained.txt (measured once, not by this run)"},
                 "hbm_view": {"algorithmic_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}, **common}
     if name.startswith("conv_tangent") or name.startswith("mlp_") or name == "gram_cholesky":
-        traffic, note = pmc_traffic("f32", B) if name == "conv_tangent_t9_ci64_co64" else (None, None)
+        traffic, note = pmc_traffic("f32", B) if (name == "conv_tangent_t9_ci64_co64" and pmc) else (None, None)
         return {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": note, "kernel": f"{name} (fp32 MFMA)",
                 "hbm_view": {"algorithmic_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}, **common}
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
             "kernel": name, **common}
+
+
+class Workload:
+    """One BASELINE configuration on this rank: model, synthetic shard, elbo kwargs."""
+
+    def __init__(self, config, B, rank, device):
+        self.config = config
+        self.dataset, over, _, self.off, self.label = CONFIGS[config]
+        self.cfg, self.schema, self.shape, self.sd, self.density = make_model(device, dataset=self.dataset, overrides=over)
+        dequant = self.schema[0]["type"] == "dequantization"
+        self.inner = self.density.module.density if dequant else self.density     # noise is part of the synthetic input
+        self.B, self.rank, self.device = B, rank, device
+        self.x = synth_batch(self.dataset, self.shape, B, rank, device)
+        self.kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=self.off, likelihood_wt=1., metric_wt=1.)
+
+
+def eval_timed(wl, world, steps, warmup, timer_select=None, graph=None):
+    """W untimed + K timed ``elbo`` steps bracketed by barrier + synchronize; returns (max-over-ranks seconds, last loss,
+    per-kernel HIP-event rows or None, world size the process group reported)."""
+    import torch
+    import torch.distributed as dist
+    from cmf_amd import engine as E
+    from cmf_amd.distributed import allreduce_mean_elbo
+
+    def step():
+        out = graph(wl.x) if graph is not None else wl.inner.elbo(wl.x, **wl.kw)
+        return allreduce_mean_elbo(out["elbo"])          # (sum, count) all-reduce; plain mean on one rank
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            step()
+        if timer_select is not None:
+            E.TIMER = E.KernelTimer(timer_select)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        fence()
+        dt = time.perf_counter() - t0
+    rows = E.TIMER.by_name() if E.TIMER is not None else None
+    E.TIMER = None
+    tmax = torch.tensor([dt], device=wl.device, dtype=torch.float64)
+    seen = 1
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        seen = dist.get_world_size()
+    return float(tmax.item()), loss, rows, seen
+
+
+def capture_graph(wl):
+    """ElboGraph of the workload's step, or (None, reason) when the capture fails (the run then times eager launches)."""
+    import torch
+    from cmf_amd.graphs import ElboGraph
+    try:
+        with torch.no_grad():
+            return ElboGraph(wl.inner, wl.x, **wl.kw), None
+    except Exception as e:                                  # noqa: BLE001
+        torch.cuda.synchronize()
+        print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr, flush=True)
+        return None, f"{type(e).__name__}: {e}"
+
+
+HIDDEN_CONV = "conv_tangent_t9_ci64_co64"        # KernelTimer name of the dominant kernel family of the image configurations
+
+
+def eval_leg(name, config, B, rank, world, device, steps, warmup, precision, scaling, graph=False, hutchinson=False):
+    """A secondary evaluation measurement inside the same process (group): returns the sub-object for rank 0's line."""
+    import torch
+    wl = Workload(config, B, rank, device)
+    if hutchinson:
+        wl.density.train()
+    g = None
+    if graph:
+        g, why = capture_graph(wl)
+        graph = g is not None
+    select = None if graph else ((lambda n: n == HIDDEN_CONV) if config in ("c3", "c5") else (lambda n: True))
+    dt, loss, rows, seen = eval_timed(wl, world, steps, warmup, select, g)
+    if graph:                                           # replayed graphs cannot carry events: eager steps for the roofline
+        _, _, rows, _ = eval_timed(wl, world, 2, 1, lambda n: True, None)
+    out = None
+    if rank == 0:
+        out = {"metric": METRICS[config] + (" (train-mode Hutchinson S=4 + CG)" if hutchinson else ""),
+               "value": B * world * steps / dt, "unit": "evals/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+               "per_gpu_batch": B, "global_batch": B * world, "n_gpus": world, "ranks_seen": seen, "scaling": scaling,
+               "config": {"workload": wl.label + (", HIP-graph replay" if graph else ""), "loss_mean": float(loss)}}
+        if rows:
+            kname, n, ms, fl, by = dominant(rows)
+            step_ms = 1e3 * dt if not graph else sum(r[1] for r in rows.values())
+            out["roofline"] = roofline_of(kname, n, ms, fl, by, step_ms, precision, B, pmc=(config == "c3"))
+    del wl, g
+    torch.cuda.empty_cache()
+    return out
+
+
+def init_group(args, world, device):
+    """RCCL (or gloo, rehearsal) process group; an initialisation failure ends THIS rank with its reason on stderr and a
+    non-zero code (the launcher then stops the others): nothing is re-executed in a process that has touched the GPU."""
+    import torch
+    import torch.distributed as dist
+    try:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)                              # the first collective is where RCCL builds its rings
+        torch.cuda.synchronize()
+        if int(probe.item()) != world:
+            raise RuntimeError(f"all-reduce over {world} ranks returned {probe.item()}")
+    except Exception as e:                                  # noqa: BLE001 -- anything here is fatal for the measurement
+        print(f"[bench] rank {os.environ.get('RANK', '?')}: {args.backend} process group failed: {type(e).__name__}: {e}",
+              file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 def run_rank(args):
@@ -306,75 +480,71 @@ def run_rank(args):
     device = torch.device("cuda", 0 if args.share_gpu else local)
     torch.cuda.set_device(device)
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(args.backend)
+        init_group(args, world, device)
 
     from cmf_amd import engine as E
-    from cmf_amd.distributed import allreduce_mean_elbo
     E.TANGENT_PRECISION = args.precision
     E.PRIMAL_PRECISION = args.primal_precision
-    dataset, over, _, off, label = CONFIGS[args.config]
-    cfg, schema, shape, sd, density = make_model(device, dataset=dataset, overrides=over)
-    inner = density.module.density if schema[0]["type"] == "dequantization" else density   # noise is part of the synthetic input
     B = args.batch // world if args.strong else args.batch
-    x = synth_batch(dataset, shape, B, rank, device)
-    kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=off, likelihood_wt=1., metric_wt=1.)
+    wl = Workload(args.config, B, rank, device)
+    cfg, schema, shape, sd, density, inner, x, kw = wl.cfg, wl.schema, wl.shape, wl.sd, wl.density, wl.inner, wl.x, wl.kw
+    dataset, off, label = wl.dataset, wl.off, wl.label
     if args.hutchinson:
         assert args.config == "c5", "--hutchinson is C5's train-mode stochastic log-det"
         density.train()                                      # non_square.py:131-138: train mode selects hutch_with_cg
 
     if args.train:
-        return train_bench(args, inner, x, B, rank, world, device, off)
-
-    graph = None
-    if args.graph:
-        from cmf_amd.graphs import ElboGraph
-        with torch.no_grad():
-            graph = ElboGraph(inner, x, **kw)
-
-    def step():
-        out = graph(x) if graph is not None else inner.elbo(x, **kw)
-        return allreduce_mean_elbo(out["elbo"])          # (sum, count) all-reduce; plain mean on one rank
-
-    def fence():
+        line = train_leg(args.steps, args.warmup, args.config, inner, x, B, rank, world, device, off)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.destroy_process_group()
+        return
 
-    def timed(steps, warmup, timer_select=None):
-        with torch.no_grad():
-            for _ in range(warmup):
-                step()
-            if timer_select is not None:
-                E.TIMER = E.KernelTimer(timer_select)
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                loss = step()
-            fence()
-            dt = time.perf_counter() - t0
-        rows = E.TIMER.by_name() if E.TIMER is not None else None
-        E.TIMER = None
-        return dt, loss, rows
+    graph, graph_note = None, None
+    if args.graph:
+        graph, graph_note = capture_graph(wl)
+        args.graph = graph is not None
 
     # the headline keeps its round-1 definition: only the dominant kernel family carries events inside the timed region
     select = None
     if not args.no_kernel_timer and graph is None:
-        select = (lambda name: name == "conv_tangent_t9_ci64_co64") if args.config in ("c3", "c5") else (lambda name: True)
-    dt, loss, rows = timed(args.steps, args.warmup, select)
+        select = (lambda name: name == HIDDEN_CONV) if args.config in ("c3", "c5") else (lambda name: True)
+    dt, loss, rows, seen = eval_timed(wl, world, args.steps, args.warmup, select, graph)
     if graph is not None and not args.no_kernel_timer:       # replayed graphs cannot carry events: eager steps, outside the timed region
-        g_, graph = graph, None
-        _, _, rows = timed(3, 1, lambda name: True)
-        graph = g_
+        _, _, rows, _ = eval_timed(wl, world, 3, 1, lambda name: True, None)
 
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    seen = 1
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        seen = dist.get_world_size()
-    dt = float(tmax.item())
+    # secondary measurements of the default command (SURVEY 8d "Secondary: train-mode fwd+bwd steps/s; per-stage times"; VERDICT r2
+    # items 3 / 4): same process (group), after the headline's timed region, each with its own barrier + synchronize bracket
+    default_run = (args.config == "c3" and not args.strong and not args.hutchinson and not args.no_legs and args.precision == "bf16x3")
+    legs = {}
+    if default_run and world > 1:
+        # BASELINE configs[3]: the SAME global batch of 512 sharded over the ranks; configs[4]: CIFAR d=128, 32 samples per GPU
+        legs["strong_c3"] = eval_leg("strong_c3", "c3", max(1, 512 // world), rank, world, device, args.leg_steps, 1, args.precision, "strong",
+                                     graph=args.graph)
+        legs["c5"] = eval_leg("c5", "c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph)
+    f32 = None
+    if default_run and world == 1:
+        if not args.no_f32_exact:
+            # the same workload with the hidden tangent convs on exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): 3 timed steps
+            E.TANGENT_PRECISION = "f32"
+            dt32, _, rows32, _ = eval_timed(wl, 1, 3, 1, None if args.no_kernel_timer else (lambda name: name == HIDDEN_CONV), None)
+            E.TANGENT_PRECISION = args.precision
+            f32 = {"value": 3 * B / dt32, "unit": "evals/s", "steps": 3, "warmup": 1, "ms_per_step": 1e3 * dt32 / 3, "dtype": "f32"}
+            if rows32:
+                name, n, ms, fl, by = dominant(rows32)
+                tf = fl / (ms * 1e-3) / 1e12
+                f32.update(kernel="conv_tangent_kernel<9,4,7> (fp32 MFMA)", kernel_avg_ms=ms / n, kernel_tflops=tf,
+                           peak=FP32_MFMA_PEAK_TFLOPS, frac=tf / FP32_MFMA_PEAK_TFLOPS)
+        legs["c5"] = eval_leg("c5", "c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph)
+        legs["c2b"] = eval_leg("c2b", "c2b", 4096, rank, world, device, 20, 2, args.precision, "weak", graph=True)
+        wl5 = Workload("c5", 32, rank, device)
+        legs["c5_train"] = train_leg(args.leg_steps, 1, "c5", wl5.inner, wl5.x, 32, rank, world, device, wl5.off)
+        del wl5
+        torch.cuda.empty_cache()
+        # last on this model: the optimiser steps change its weights (C3 model, the reference's 64-sample C4 shard)
+        x64 = synth_batch(dataset, shape, 64, rank, device)
+        legs["train"] = train_leg(args.leg_steps, 1, "c3", inner, x64, 64, rank, world, device, off)
 
     if rank == 0:
         total = B * world * args.steps
@@ -394,21 +564,16 @@ def run_rank(args):
         if rows:
             name, n, ms, fl, by = dominant(rows)
             step_ms = 1e3 * dt if not args.graph else sum(r[1] for r in rows.values())
-            line["roofline"] = roofline_of(name, n, ms, fl, by, step_ms, args.precision, B)
+            line["roofline"] = roofline_of(name, n, ms, fl, by, step_ms, args.precision, B, pmc=(args.config == "c3"))
             if args.graph:
                 line["roofline"]["note"] = "kernel events from 3 eager steps after the timed graph replays; share_of_step = share of GPU kernel time"
-        if world == 1 and args.config == "c3" and not args.no_f32_exact and args.precision == "bf16x3":
-            # the same workload with the hidden tangent convs on exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): 3 timed steps
-            E.TANGENT_PRECISION = "f32"
-            dt32, _, rows32 = timed(3, 1, None if args.no_kernel_timer else (lambda name: name == "conv_tangent_t9_ci64_co64"))
-            E.TANGENT_PRECISION = args.precision
-            f32 = {"value": 3 * B / dt32, "unit": "evals/s", "steps": 3, "warmup": 1, "ms_per_step": 1e3 * dt32 / 3, "dtype": "f32"}
-            if rows32:
-                name, n, ms, fl, by = dominant(rows32)
-                tf = fl / (ms * 1e-3) / 1e12
-                f32.update(kernel="conv_tangent_kernel<9,4,7> (fp32 MFMA)", kernel_avg_ms=ms / n, kernel_tflops=tf,
-                           peak=FP32_MFMA_PEAK_TFLOPS, frac=tf / FP32_MFMA_PEAK_TFLOPS)
+        if graph_note:
+            line["config"]["graph_capture_failed"] = graph_note
+        if f32 is not None:
             line["f32_exact"] = f32
+        for k, v in legs.items():
+            if v is not None:
+                line[k] = v
         if world == 1 and args.cpu_batch > 0:
             line["cpu_baseline"] = cpu_baseline(schema, shape, {k: v.cpu() for k, v in sd.items()}, args.cpu_batch, dataset, off, label)
         print(json.dumps(line), flush=True)

@@ -104,6 +104,7 @@ SIGNATURES = {
     "cmf_made_mask_weight": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp]),
     "cmf_hutch_metric": (_i, [_fp, _i, _i, _i, _fp, _fp, _fp]),
     "cmf_hutch_cotangent": (_i, [_fp, _fp, _fp, _i, _i, _i, _fp, _fp, _fp, _fp, _fp]),
+    "cmf_hutch_lowrank_cotangent": (_i, [_fp, _i, _i, _i, _fp, _fp, _i, _fp, _fp]),
 }
 
 _lib = None

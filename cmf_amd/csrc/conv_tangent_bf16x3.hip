@@ -728,6 +728,16 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         }
       }
       if (FIRST && s == 0) wait_res(p, false);
+#ifdef CMF_DBG_MFMAORD
+      // experiment: product-major order -- the X fragment (srcA) stays on the operand bus for CW consecutive MFMAs and
+      // consecutive MFMAs never share an accumulator
+#pragma unroll
+      for (int c = 0; c < CW; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], al[s][c], acc[p][c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
+#else
 #pragma unroll
       for (int c = 0; c < CW; ++c) {
         // D[row = Jacobian column][col = output channel] = X-fragment (as A) x W-fragment (as B): each lane then
@@ -736,6 +746,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
         acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
       }
+#endif
       if (LAST && s == KS - 1) {
         store_pixel(cur, p);
         init_pixel(nxt, nxt_rrs, p);

@@ -155,15 +155,16 @@ __global__ __launch_bounds__(256) void hutch_value_kernel(const float* __restric
 
 // Metric term on the Hutchinson product (non_square.py:87-100 applied to the third return value of :253-258, W = G eps of
 // shape (B, d, S)): g_kk = diagonal(W) -> l1_diag = sum_k |W_kk|;  g_ij = W.masked_select(~eye(d)).view(B, d(d-1)) -> l1_off =
-// sum_{i != j} |W_ij|.  The reference's view() only works for S == d, which is the launcher's precondition.
-__global__ __launch_bounds__(256) void hutch_metric_kernel(const float* __restrict__ w, int d, float* __restrict__ l1_off,
+// sum_{i != j} |W_ij|.  The reference's view() of the off-diagonal entries only works for S == d (the launcher's precondition for
+// l1_off); its diagonal branch (:87-92) takes torch.diagonal of the (B, d, S) product, valid for any S: min(d, S) entries.
+__global__ __launch_bounds__(256) void hutch_metric_kernel(const float* __restrict__ w, int d, int S, float* __restrict__ l1_off,
                                                             float* __restrict__ l1_diag) {
   __shared__ float red[16];
-  const long long o = (long long)blockIdx.x * d * d;
+  const long long o = (long long)blockIdx.x * d * S;
   float off = 0.f, dg = 0.f;
-  for (int i = threadIdx.x; i < d * d; i += 256) {
+  for (int i = threadIdx.x; i < d * S; i += 256) {
     const float a = fabsf(w[o + i]);
-    if (i / d == i % d) dg += a; else off += a;
+    if (i / S == i % S) dg += a; else off += a;               // diagonal(W, dim1=-2, dim2=-1): min(d, S) entries
   }
   off = block_sum(off, red);
   dg = block_sum(dg, red);
@@ -209,7 +210,41 @@ __global__ __launch_bounds__(256) void hutch_cotangent_kernel(const float* __res
   }
 }
 
+// LOW-RANK form of the same cotangent (S << d).  With V = [u_1..u_S | eps_1..eps_S | e_0..e_{K-1}] (d x n, n = 2S + K) and
+// P = J V (one n-column tangent sweep), the train-mode objective is a sum of inner products of COLUMNS of P:
+//   value_b   = 1/S sum_s <P_s, P_{S+s}>                    (u detached: V is a constant)
+//   l1_diag_b = sum_{k < K} |<P_{2S+k}, P_{S+k}>|,  K = min(d, S)      (W_kk = e_k^T J^T J eps_k)
+// so d objective / d (P^T P) is the n x n matrix  C[s][S+s] = g_val/S,  C[2S+k][S+k] = g_diag sign(W_kk)  and the cotangent of P is
+// P (C + C^T): cmf_gram_backward_matrix on the n-column stack.  One thread per matrix entry.
+__global__ void hutch_lowrank_cotangent_kernel(const float* __restrict__ w, int d, int S, int n, const float* __restrict__ g_val,
+                                               const float* __restrict__ g_diag, float* __restrict__ C, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx % n), i = (int)((idx / n) % n);
+  const long long b = idx / ((long long)n * n);
+  float v = 0.f;
+  if (i < S && j == S + i) v = g_val ? g_val[b] / (float)S : 0.f;
+  if (g_diag && i >= 2 * S && j == S + (i - 2 * S)) {
+    const int k = i - 2 * S;
+    const float wkk = w[(b * d + k) * S + k];
+    v = g_diag[b] * (wkk > 0.f ? 1.f : (wkk < 0.f ? -1.f : 0.f));
+  }
+  C[idx] = v;
+}
+
 }  // namespace
+
+extern "C" int cmf_hutch_lowrank_cotangent(const float* w, int d, int S, int B, const float* g_val, const float* g_diag, int n,
+                                           float* cmat, void* stream) {
+  if (!cmat || d <= 0 || d > 128 || S <= 0 || S > 128 || B <= 0) return CMF_EINVAL;
+  const int K = g_diag ? (d < S ? d : S) : 0;
+  if (n != 2 * S + K || (g_diag && !w)) return CMF_EINVAL;
+  const long long total = (long long)B * n * n;
+  hipLaunchKernelGGL(hutch_lowrank_cotangent_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, d, S,
+                     n, g_val, g_diag, cmat, total);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int cmf_hutch_cg(const float* jtj, const float* eps, int d, int S, int B, int max_iter, int min_iter, float tol,
                             float* u, float* w, float* val, int* iters, void* stream) {
@@ -237,8 +272,9 @@ extern "C" int cmf_hutch_cg(const float* jtj, const float* eps, int d, int S, in
 }
 
 extern "C" int cmf_hutch_metric(const float* w, int d, int S, int B, float* l1_off, float* l1_diag, void* stream) {
-  if (!w || d <= 0 || d > 128 || S != d || B <= 0 || (!l1_off && !l1_diag)) return CMF_EINVAL;
-  hipLaunchKernelGGL(hutch_metric_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, w, d, l1_off, l1_diag);
+  if (!w || d <= 0 || d > 128 || S <= 0 || S > 128 || B <= 0 || (!l1_off && !l1_diag)) return CMF_EINVAL;
+  if (l1_off && S != d) return CMF_EINVAL;                       // non_square.py:98: the off-diagonal view needs a square block
+  hipLaunchKernelGGL(hutch_metric_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, w, d, S, l1_off, l1_diag);
   CMF_LAUNCH_CHECK();
   return 0;
 }
@@ -246,7 +282,8 @@ extern "C" int cmf_hutch_metric(const float* w, int d, int S, int B, float* l1_o
 extern "C" int cmf_hutch_cotangent(const float* u, const float* eps, const float* w, int d, int S, int B, const float* g_val,
                                    const float* g_off, const float* g_diag, float* M, void* stream) {
   if (!u || !eps || !M || d <= 0 || d > 128 || S <= 0 || S > 128 || B <= 0) return CMF_EINVAL;
-  if ((g_off || g_diag) && (!w || S != d)) return CMF_EINVAL;
+  if ((g_off || g_diag) && !w) return CMF_EINVAL;
+  if (g_off && S != d) return CMF_EINVAL;
   const size_t lds = (size_t)2 * d * (S + 1) * sizeof(float);
   if (lds > 48 * 1024) {
     hipError_t e = cmf_set_dynamic_lds((const void*)hutch_cotangent_kernel, (int)lds);

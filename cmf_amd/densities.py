@@ -472,14 +472,18 @@ class FlowProgram:
         return z, out.to_dense(S).contiguous()
 
     # -- training: decode with saved state, and its backward -------------------------------
-    def decode_train(self, z_low, tangents=True, keep=True):
+    def decode_train(self, z_low, tangents=True, keep=True, eps=None, nc=None):
         """``decode(z_low, tangents)`` keeping every coupling layer's context (``keep=False``: only its inputs, the rest is
-        recomputed layer by layer in ``decode_backward``); returns (x_hat, T, ctx)."""
+        recomputed layer by layer in ``decode_backward``); returns (x_hat, T, ctx).  ``eps`` (B, d, n): the sweep carries the n
+        directions J eps instead of the d Jacobian columns (low-rank Hutchinson backward), in ``nc`` >= n column slots."""
         B, dev = z_low.shape[0], z_low.device
         N = int(np.prod(self.tail.x_shape))
         scatter = self.tail.scatter_index(dev)
         z = E.gather_primal(z_low.contiguous(), scatter, N).view(B, *self.tail.x_shape)
-        T = E.seed_tangent(B, N, E.ceil16(self.d), self.layout, scatter, self.d, dev) if tangents else None
+        ncols = self.d if eps is None else eps.shape[2]
+        nc = E.ceil16(ncols) if nc is None else int(nc)
+        assert nc % 16 == 0 and nc >= ncols
+        T = E.seed_tangent(B, N, nc, self.layout, scatter, self.d, dev, eps=eps) if tangents else None
         ctx = []
         for m in reversed(self.layers):
             if isinstance(m, AffineCouplingBijection):
@@ -648,7 +652,7 @@ class _ElboFunction(torch.autograd.Function):
     def forward(ctx, head, x, kw, pre, box, *params):
         elbo, state = head.train_forward(x, pre_logjac=pre, **kw)
         ctx.head, ctx.state, ctx.params = head, state, params
-        box["prior-dict"] = state["prior_dict"]            # same keys / nesting as the no-grad path
+        box["prior-dict"] = state["prior_dict"]            # same keys / nesting as the no-grad path (head.nested_prior_dict too)
         return elbo
 
     @staticmethod
@@ -762,7 +766,7 @@ class NonSquareHeadDensity(Density):
             self.last_gram = g
             if hutch:
                 # train mode: Hutchinson + CG surrogate (non_square.py:131-138, :203-258) on the explicit Gram matrix
-                self._check_hutchinson_metric(add_diag or add_off)
+                self._check_hutchinson_metric(add_off)
                 eps = self._hutchinson_probes(B, dev)
                 val, u, w, iters = E.hutch_cg(g.jtj, eps, self.max_cg_iterations or prog.d, self.cg_tolerance)
                 self.last_hutchinson = {"eps": eps, "u": u, "w": w, "iterations": iters, "value": val}
@@ -784,11 +788,12 @@ class NonSquareHeadDensity(Density):
                               B, dev)
         return {"elbo": elbo, "prior-dict": prior_dict}
 
-    def _check_hutchinson_metric(self, wanted):
+    def _check_hutchinson_metric(self, offdiagonal):
         """The reference reshapes the off-diagonal entries of the (B, d, S) product to (B, d (d - 1)) (non_square.py:98): only
-        S == d survives that view (the diagonal variant too reads ``diagonal(dim1=-2, dim2=-1)`` of a square block)."""
-        if wanted and self.num_hutchinson_samples != self.program.d:
-            raise ValueError("metric regularisation with hutch_with_cg needs num_hutchinson_samples == "
+        S == d survives that view.  The DIAGONAL variant (:87-92) takes ``torch.diagonal(dim1=-2, dim2=-1)`` of the rectangular
+        block, which is valid for any S and sums min(d, S) entries -- e.g. C5 with S = 4 plus ``g_kk_loss`` trains."""
+        if offdiagonal and self.num_hutchinson_samples != self.program.d:
+            raise ValueError("off-diagonal metric regularisation with hutch_with_cg needs num_hutchinson_samples == "
                              "latent_dimension (the reference fails at non_square.py:98 otherwise)")
 
     def _hutchinson_probes(self, B, dev):
@@ -864,12 +869,57 @@ class NonSquareHeadDensity(Density):
     # ------------------------------------------------------------------------------------------
     # training: forward with saved state, backward on the HIP kernels
     # ------------------------------------------------------------------------------------------
-    def head_terms_forward(self, z_low, tangents=True, hutch_eps=None, keep=True):
+    #: None = automatic: the train-mode Hutchinson backward runs through the 2 S (+ min(d, S)) directions {u_s, eps_s (, e_k)}
+    #: instead of all d Jacobian columns whenever that is fewer column slots; False = always differentiate the d-column sweep
+    hutch_lowrank = None
+    #: column slots of the low-rank sweep are padded to a multiple of this (32: the split-precision weight-gradient kernel
+    #: contracts two 16-column slices per MFMA; 16 runs the fp32 weight-gradient kernel on half the columns)
+    HUTCH_LOWRANK_NC = 32
+
+    def _hutch_lowrank_columns(self, add_diag=False, add_off=False):
+        """(n, nc) of the low-rank sweep -- n directions in nc column slots -- or None where the d-column backward is used:
+        the off-diagonal metric term needs S == d (every column anyway), or nothing would be saved."""
+        if self.hutch_lowrank is False or add_off:
+            return None
+        d, S = self.program.d, self.num_hutchinson_samples
+        n = 2 * S + (min(d, S) if add_diag else 0)
+        q = int(self.HUTCH_LOWRANK_NC)
+        nc = -(-n // q) * q
+        return (n, nc) if nc < E.ceil16(d) else None
+
+    def head_terms_forward(self, z_low, tangents=True, hutch_eps=None, keep=True, add_diag=False, add_off=False):
         """Decode (with the Jacobian stack) keeping every layer's context, Gram + Cholesky; returns the state
         ``head_terms_backward`` consumes.  ``hutch_eps`` (B, d, S): also run the Hutchinson + CG surrogate of
-        non_square.py:203-258 on the explicit Gram matrix (train mode of ``log_jacobian_method = "hutch_with_cg"``)."""
+        non_square.py:203-258 on the explicit Gram matrix (train mode of ``log_jacobian_method = "hutch_with_cg"``).
+
+        Low-rank form (S << d, ``_hutch_lowrank_columns``): the reference builds its graph ONLY through ``w = J^T J eps`` for the
+        S probes, ``u`` detached (non_square.py:241-256), so the parameter gradients need the tangents in the 2 S directions
+        {u_s, eps_s} alone: dJ = J (M + M^T) = sum_s (J u_s) eps_s^T + (J eps_s) u_s^T with M = 1/S sum_s u_s eps_s^T.  The
+        d-column sweep that feeds the explicit Gram matrix then runs WITHOUT saved state, and a second, n-column sweep seeded
+        with V = [u | eps (| e_k for the diagonal metric term)] is the one kept for the backward pass."""
         E.require_gpu(z_low)
         with torch.no_grad():
+            low = self._hutch_lowrank_columns(add_diag, add_off) if (tangents and hutch_eps is not None) else None
+            if low is not None:
+                prog, d, S = self.program, self.program.d, hutch_eps.shape[2]
+                _, T = prog.decode(z_low.detach(), tangents=True)                 # all d columns, nothing kept
+                gr = E.gram_cholesky(T, d, 1)                                       # the Hutchinson branch never factorises
+                del T
+                self.last_gram = gr
+                val, u, w, iters = E.hutch_cg(gr.jtj, hutch_eps, self.max_cg_iterations or d, self.cg_tolerance)
+                hutch = {"eps": hutch_eps, "u": u, "w": w, "iterations": iters, "value": val, "lowrank": low, "diag": add_diag}
+                if add_diag:
+                    hutch["l1_off"], hutch["l1_diag"] = E.hutch_metric(w)
+                self.last_hutchinson = hutch
+                n, nc = low
+                V = torch.zeros(z_low.shape[0], d, n, dtype=torch.float32, device=z_low.device)
+                V[:, :, :S] = u
+                V[:, :, S:2 * S] = hutch_eps
+                if add_diag:
+                    k = torch.arange(min(d, S), device=z_low.device)
+                    V[:, k, 2 * S + k] = 1.0
+                x_hat, TV, ctx = prog.decode_train(z_low.detach(), True, keep, eps=V, nc=nc)
+                return {"x_hat": x_hat, "T": TV, "ctx": ctx, "gram": gr, "hutch": hutch}
             x_hat, T, ctx = self.program.decode_train(z_low.detach(), tangents, keep)
             gr = hutch = None
             if tangents:
@@ -883,7 +933,7 @@ class NonSquareHeadDensity(Density):
                 if hutch_eps is not None:
                     val, u, w, iters = E.hutch_cg(gr.jtj, hutch_eps, self.max_cg_iterations or self.program.d, self.cg_tolerance)
                     hutch = {"eps": hutch_eps, "u": u, "w": w, "iterations": iters, "value": val}
-                    if hutch_eps.shape[2] == self.program.d:
+                    if add_diag or add_off or hutch_eps.shape[2] == self.program.d:
                         hutch["l1_off"], hutch["l1_diag"] = E.hutch_metric(w)
                     self.last_hutchinson = hutch
         return {"x_hat": x_hat, "T": T, "ctx": ctx, "gram": gr, "hutch": hutch}
@@ -906,8 +956,14 @@ class NonSquareHeadDensity(Density):
                 # non_square.py:236-247): d value / d G = mean_s u_s eps_s^T, handed over as an explicit matrix
                 # and the metric term on the product W = G eps (S == d): d |W_is| / d G = sign(W_is) e_i eps_s^T
                 h = st["hutch"]
-                M = E.hutch_cotangent(h["u"], h["eps"], h["w"], g_logdet, g_l1off, g_l1diag)
-                Ct = E.gram_backward_matrix(T, M)
+                if h.get("lowrank") is not None:
+                    # T is the n-column sweep P = J [u | eps (| e_k)]: the objective is a sum of inner products of its columns
+                    assert g_l1off is None, "the off-diagonal metric term differentiates all d columns"
+                    Cm = E.hutch_lowrank_cotangent(h["w"], h["eps"].shape[2], g_logdet, g_l1diag if h["diag"] else None)
+                    Ct = E.gram_backward_matrix(T, Cm)
+                else:
+                    M = E.hutch_cotangent(h["u"], h["eps"], h["w"], g_logdet, g_l1off, g_l1diag)
+                    Ct = E.gram_backward_matrix(T, M)
             elif tangents:
                 Ct = E.gram_backward(T, gr.jtj, g_logdet, g_l1off, g_l1diag)
             dx = torch.zeros_like(x_hat)
@@ -941,13 +997,16 @@ class NonSquareHeadDensity(Density):
             raise ValueError("the M-flow head has no J^T J: metric regularisation is not defined for it (non_square.py:87-100)")
         hutch = want_jac and self.training and self.log_jacobian_method == "hutch_with_cg"     # non_square.py:131-138
         if hutch:
-            self._check_hutchinson_metric(add_diagonal_metric_reg or add_offdiagonal_metric_reg)
+            self._check_hutchinson_metric(add_offdiagonal_metric_reg)
+        lowrank = hutch and self._hutch_lowrank_columns(add_diagonal_metric_reg, add_offdiagonal_metric_reg) is not None
         keep = True
         if want_jac:
-            nc = E.ceil16(prog.d)
+            # the low-rank Hutchinson backward keeps an n-column sweep (the d-column one runs without saved state first)
+            nc = self._hutch_lowrank_columns(add_diagonal_metric_reg, add_offdiagonal_metric_reg)[1] if lowrank else E.ceil16(prog.d)
             free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
             keep = (B * prog.train_bytes_per_sample(nc) <= 0.8 * free) if self.recompute is None else not self.recompute
-            need = B * prog.train_bytes_per_sample(nc, recompute=not keep)
+            need = B * max(prog.train_bytes_per_sample(nc, recompute=not keep),
+                           prog.tangent_bytes_per_sample(E.ceil16(prog.d)) if lowrank else 0)
             if need > free:
                 raise RuntimeError(f"cmf_amd: a training step on {B} samples keeps ~{need / 2**30:.0f} GiB of tangents for the backward "
                                    f"pass (recomputation per coupling layer {'on' if not keep else 'off'}) but {free / 2**30:.0f} GiB "
@@ -956,7 +1015,7 @@ class NonSquareHeadDensity(Density):
             x = x.contiguous()
             z_low, low_elbo, u, ctx, pctx = prog.encode_train(x)
             head = self.head_terms_forward(z_low, tangents=want_jac, hutch_eps=self._hutchinson_probes(B, dev) if hutch else None,
-                                           keep=keep)
+                                           keep=keep, add_diag=add_diagonal_metric_reg, add_off=add_offdiagonal_metric_reg)
             gr = head["gram"]
             rec = E.recon_sqerr(head["x_hat"], x) if add_reconstruction else None
             l1 = logdet = None
@@ -966,7 +1025,12 @@ class NonSquareHeadDensity(Density):
                 logdet = head["hutch"]["value"] if hutch else gr.logdet
             elbo = E.elbo_combine(low_elbo if want_lik else None, logdet, rec, l1, pre_logjac,
                                   likelihood_wt, self.regularization_param, metric_wt, B, dev)
-        prior_dict = {"elbo": low_elbo.view(B, 1), "low-dim-x": z_low}
+        if self.nested_prior_dict:
+            # opt-in: the reference's nested chain, from one more (no-grad) encode pass like the evaluation path's
+            with torch.no_grad():
+                prior_dict = prog.encode_nested(x)[3]
+        else:
+            prior_dict = {"elbo": low_elbo.view(B, 1), "low-dim-x": z_low}
         state = dict(x=x, z_low=z_low, u=u, ctx=ctx, pctx=pctx, head=head, want_lik=want_lik, want_jac=want_jac, rec=add_reconstruction,
                      prior_dict=prior_dict,
                      diag=add_diagonal_metric_reg, off=add_offdiagonal_metric_reg, wl=float(likelihood_wt), wm=float(metric_wt))

@@ -94,11 +94,6 @@ TANGENT_PRECISION = "bf16x3"
 PRIMAL_PRECISION = "f32"
 
 
-#: batches below this many samples run the ResNet couplers' primal pass on cmf_conv_primal (standard layout, one launch grid over
-#: samples x pixel tiles) instead of 16-sample groups through the tangent-conv kernels
-GROUPED_PRIMAL_MIN_BATCH = 16
-
-
 def _use_bf16x3(taps, cin, W, transpose, H=None, cout=64):
     return TANGENT_PRECISION == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
 
@@ -418,7 +413,6 @@ def accumulate_any(dst, src):
     """dst += src for flat fp32 tensors of any length: cmf_tanh_backward with a = 0 computes (dst + src) (1 - 0) in place."""
     n = dst.numel()
     assert src.numel() == n
-    zero = torch.zeros(1, dtype=torch.float32, device=dst.device)
     if n % 4 == 0 and dst.data_ptr() % 16 == 0 and src.data_ptr() % 16 == 0:
         return accumulate(dst, src)
     # odd sizes: elementwise kernel with a broadcast-free formulation: out = (dh + extra) * (1 - a^2) needs a of length n
@@ -518,9 +512,11 @@ def hutch_cg(jtj, eps, max_iter, tol, min_iter=None):
 
 
 def hutch_metric(w):
-    """(l1_off, l1_diag) of the Hutchinson product W = (J^T J) eps, (B, d, S) with S == d (non_square.py:87-100 on :253-258)."""
+    """(l1_off, l1_diag) of the Hutchinson product W = (J^T J) eps, (B, d, S) (non_square.py:87-100 on :253-258).  The
+    off-diagonal sum exists only for S == d (the reference's ``view`` at :98; None otherwise); the diagonal one is
+    ``torch.diagonal`` of the rectangular block: min(d, S) entries (:87-92)."""
     B, d, S = w.shape
-    off = torch.empty(B, dtype=torch.float32, device=w.device)
+    off = torch.empty(B, dtype=torch.float32, device=w.device) if S == d else None
     diag = torch.empty(B, dtype=torch.float32, device=w.device)
     _lib.check(_lib.load().cmf_hutch_metric(_p(w.contiguous()), d, S, B, _p(off), _p(diag), _stream()), "cmf_hutch_metric")
     return off, diag
@@ -536,6 +532,18 @@ def hutch_cotangent(u, eps, w, g_val=None, g_off=None, g_diag=None):
     return M
 
 
+def hutch_lowrank_cotangent(w, S, g_val=None, g_diag=None):
+    """(B, n, n) cotangent of P^T P for the n-column sweep P = J [u | eps | e_0..e_{K-1}] of the low-rank Hutchinson backward
+    (``cmf_hutch_lowrank_cotangent``); n = 2 S + (min(d, S) if g_diag is given)."""
+    B, d = w.shape[0], w.shape[1]
+    n = 2 * S + (min(d, S) if g_diag is not None else 0)
+    M = torch.empty(B, n, n, dtype=torch.float32, device=w.device)
+    gs = [None if g is None else g.to(torch.float32).contiguous() for g in (g_val, g_diag)]
+    _lib.check(_lib.load().cmf_hutch_lowrank_cotangent(_p(w.contiguous()), d, S, B, *[None if g is None else _p(g) for g in gs], n,
+                                                       _p(M), _stream()), "cmf_hutch_lowrank_cotangent")
+    return M
+
+
 # --------------------------------------------------------------------------------------------------
 # NSF prior layers (SURVEY 8 f3): derived weights are cached per parameter version like the packs
 # --------------------------------------------------------------------------------------------------
@@ -543,8 +551,9 @@ def hutch_cotangent(u, eps, w, g_val=None, g_off=None, g_diag=None):
 
 class _DerivedCache:
     """Tensors computed from parameters by a kernel (masked MADE weights, L U products), rebuilt when a source parameter
-    changes (``_version`` / storage / ``PACKS.generation``, which FlatOptimizer bumps).  A rebuilt entry is a NEW tensor, so
-    the pack cache keyed on the tensor's identity follows."""
+    changes (``_version`` / storage / ``PACKS.generation``, which FlatOptimizer bumps).  A stale entry is rebuilt INTO its old
+    tensors (same identity, ``_version`` bumped by the copy), so the pack cache entry keyed on that identity is refreshed in place
+    instead of a new one piling up per optimiser step."""
 
     def __init__(self):
         self._store = {}
@@ -556,6 +565,13 @@ class _DerivedCache:
         if hit is not None and hit[0]() is sources[0] and hit[1] == ver:
             return hit[2]
         out = build()
+        if hit is not None and hit[0]() is sources[0]:
+            old, new = hit[2], out
+            olds, news = (old, new) if isinstance(old, tuple) else ((old,), (new,))
+            if len(olds) == len(news) and all(o.shape == n.shape and o.device == n.device for o, n in zip(olds, news)):
+                for o, n in zip(olds, news):
+                    o.copy_(n)
+                out = old
         if len(self._store) > 4096:
             self._store = {k: v for k, v in self._store.items() if v[0]() is not None}
         self._store[key] = (weakref.ref(sources[0]), ver, out)

@@ -271,14 +271,22 @@ int cmf_hutch_cg(const float* jtj, const float* eps, int d, int S, int B, int ma
                  float* u, float* w, float* val, int* iters, void* stream);
 /* Metric term on the Hutchinson product W = (J^T J) eps, [B][d][S] with S == d -- the third return value of
  * non_square.py:253-258 fed to :87-100:  l1_diag[b] = sum_k |W_kk|,  l1_off[b] = sum_{i != j} |W_ij|
- * (the reference's masked_select(~eye).view(B, d(d-1)) exists only for S == d).  Either output may be NULL. */
+ * (the reference's masked_select(~eye).view(B, d(d-1)) exists only for S == d: l1_off must be NULL otherwise; the diagonal branch,
+ * torch.diagonal of the (B, d, S) product at :87-92, is valid for any S and sums min(d, S) entries).  Either output may be NULL. */
 int cmf_hutch_metric(const float* w, int d, int S, int B, float* l1_off, float* l1_diag, void* stream);
 /* Cotangent of the Gram matrix for the train-mode Hutchinson objective, u detached (non_square.py:236-247):
  *   M(b) = g_val[b]/S sum_s u_s eps_s^T + sum_s (g_off[b] [i != s] + g_diag[b] [i == s]) sign(W_is) e_i eps_s^T,
  * [B][d][d]; feed it to cmf_gram_backward_matrix (dJ = J (M + M^T)).  g_val / g_off / g_diag: [B] or NULL; the metric
- * terms need w and S == d. */
+ * terms need w; g_off needs S == d. */
 int cmf_hutch_cotangent(const float* u, const float* eps, const float* w, int d, int S, int B, const float* g_val,
                         const float* g_off, const float* g_diag, float* M, void* stream);
+/* Low-rank form of the same cotangent for S << d (non_square.py:241-256 builds its graph only through J^T J eps for the S
+ * probes): with V = [u_1..u_S | eps_1..eps_S | e_0..e_{K-1}] (K = min(d, S) when g_diag is given, else 0; n = 2S + K columns) and
+ * P = J V from ONE n-column tangent sweep, the objective is a sum of inner products of columns of P and its cotangent with
+ * respect to P^T P is  cmat[b][s][S+s] = g_val[b]/S,  cmat[b][2S+k][S+k] = g_diag[b] sign(W_kk)  ([B][n][n], zero elsewhere);
+ * cmf_gram_backward_matrix(P, cmat) then yields the cotangent of P.  w [B][d][S] is read only with g_diag. */
+int cmf_hutch_lowrank_cotangent(const float* w, int d, int S, int B, const float* g_val, const float* g_diag, int n,
+                                float* cmat, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused affine-coupling layer with an MLP coupler (2-D / tabular models, low-dimensional prior flows): the whole coupler

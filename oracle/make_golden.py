@@ -150,6 +150,87 @@ def jitter_fixture(get_density, ref_get_config, ref_get_schema, expand_grid):
     np.savez_compressed(os.path.join(GOLDEN, "jitter_retry.npz"), **out)
 
 
+def head_parts(density, head, xin, dequant):
+    """(z_low, low_dim_elbo, logdet, l1_off, l1_diag, x_hat) through the reference head's own methods (non_square.py:146-188,
+    :262-296, :87-100) for the head input reached from ``xin`` (dequantisation noise already added)."""
+    y = xin.clone()
+    m = density.module.density if dequant else density.module
+    while m is not head:
+        y = m.bijection.x_to_z(y)["z"]
+        m = m.prior
+    prior_dict = head.prior.elbo(y)
+    z_low, low_elbo, _ = head._traverse_backward(y, prior_dict)
+    logdet, x_hat, jtj = head._exact_log_det_jac_and_reconstruction(z_low)
+    diag = torch.diagonal(jtj, dim1=1, dim2=2).abs().sum(1)
+    return z_low, low_elbo, logdet, jtj.abs().sum((1, 2)) - diag, diag, x_hat
+
+
+def perturbed_parts(head, z_low, delta=1e-6):
+    """The reference's OWN log-det / g_ij when its latent moves by ``delta`` relative per component, both signs: the yardstick for
+    "within rounding of a relu kink" (any fp32 encode chain lands z_low within a few ulps of the reference's).  (2, B) each."""
+    lds, offs = [], []
+    for sgn in (1.0, -1.0):
+        logdet, _, jtj = head._exact_log_det_jac_and_reconstruction(z_low * (1.0 + sgn * delta))
+        lds.append(logdet.reshape(-1))
+        offs.append(jtj.abs().sum((1, 2)) - torch.diagonal(jtj, dim1=1, dim2=2).abs().sum(1))
+    return torch.stack(lds), torch.stack(offs)
+
+
+def fp64_reference(get_density, schema, sd, x, noise, dequant):
+    """The reference evaluated in float64 on the same inputs and weights: elbo of the headline call and its parts."""
+    torch.set_default_dtype(torch.float64)      # the reference allocates with the default dtype
+    try:
+        d64 = get_density(schema, x.double())
+        d64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()
+                             if not k.endswith("bijection.mask")}, strict=False)
+        d64 = d64.double().eval()
+        with torch.no_grad():
+            inner64 = d64.module.density if dequant else d64
+            xin = (x + noise).double() if dequant else x.double()
+            out = {"elbo_0_fp64": inner64.elbo(xin.clone(), add_offdiagonal_metric_reg=True)["elbo"].numpy()}
+            z, low, logdet, off, diag, _ = head_parts(d64, find_head(d64), xin, dequant)
+            out.update(logdet_fp64=logdet.numpy(), l1_off_fp64=off.numpy(), l1_diag_fp64=diag.numpy(), low_dim_elbo_fp64=low.numpy())
+        return out
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def stats_fixture(get_density, ref_get_config, ref_get_schema, expand_grid, name="c3_mnist_stats32", B=32):
+    """32 fresh MNIST-sized inputs (the set of tests/test_gpu_parity.py::test_parity_statistics_full_mnist_model) through the
+    full-size d = 64 reference in float32 AND float64, plus the float32 reference's own sensitivity to a 1e-6 relative move of
+    its latent: per-sample yardsticks for the GPU path's error at the benchmarked size.  Only (B,)-shaped outputs are stored."""
+    from cmf_amd.recipe import fill_state_dict
+    from cmf_amd import schemas as my_schemas
+    over = {"latent_dimension": 64, "log_jacobian_method": "cholesky"}
+    cfg = expand_grid({**ref_get_config("mnist", "non-square", False), **over})[0]
+    schema = ref_get_schema(cfg)
+    shape = my_schemas.DATA_SHAPES["mnist"]
+    gen = torch.Generator().manual_seed(2024)
+    x = torch.randint(0, 256, (B, *shape), generator=gen).float()
+    noise = torch.rand(B, *shape, generator=gen)
+    torch.manual_seed(0)
+    density = get_density(schema, x)
+    sd = fill_state_dict(density.state_dict(), seed=0)
+    density.load_state_dict({k: v for k, v in sd.items() if not k.endswith("bijection.mask")}, strict=False)
+    density.eval()
+    head = find_head(density)
+    out = {"x": x.numpy().astype(np.uint8), "noise": noise.numpy()}
+    with torch.no_grad():
+        out["elbo_0"] = density.module.density.elbo(x + noise, add_offdiagonal_metric_reg=True)["elbo"].numpy()
+        z, low, logdet, off, diag, _ = head_parts(density, head, x + noise, True)
+        out.update(z_low=z.numpy(), low_dim_elbo=low.numpy(), logdet=logdet.numpy(), l1_off=off.numpy(), l1_diag=diag.numpy())
+        ld_p, off_p = perturbed_parts(head, z)
+        out.update(logdet_pert=ld_p.numpy(), l1_off_pert=off_p.numpy())
+    out.update(fp64_reference(get_density, schema, sd, x, noise, True))
+    meta = {"dataset": "mnist", "overrides": over, "batch": B, "recipe_seed": 0, "recipe_gain": None, "input_seed": 2024,
+            "perturbation": 1e-6, "state_dict": {k: [list(v.shape), str(v.dtype)] for k, v in sd.items()}}
+    out["meta"] = np.array(json.dumps(meta))
+    path = os.path.join(GOLDEN, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    e = np.abs(out["logdet"].ravel() - out["logdet_fp64"].ravel()) / np.abs(out["logdet_fp64"].ravel())
+    print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.1f} KiB); reference fp32 vs fp64 log-det: max {e.max():.2e} median {np.median(e):.2e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -161,6 +242,8 @@ def main():
 
     if not args.only or args.only == "jitter_retry":
         jitter_fixture(get_density, ref_get_config, ref_get_schema, expand_grid)
+    if not args.only or args.only == "c3_mnist_stats32":
+        stats_fixture(get_density, ref_get_config, ref_get_schema, expand_grid)
     for name, (dataset, over, B, *opt) in CASES.items():
         if args.only and args.only != name:
             continue
@@ -249,19 +332,12 @@ def main():
             w, _ = head._jac_transpose_jac_vec(rep, vec, create_graph=False)
             out["hutch_eps"] = eps.numpy()
             out["hutch_jtj_eps"] = w.reshape(B, S, -1).transpose(1, 2).detach().numpy()
-            # fp64 reference evaluation of the headline call (tolerance analysis)
-            torch.set_default_dtype(torch.float64)      # the reference allocates with the default dtype
-            try:
-                d64 = get_density(schema, x.double())
-                d64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()
-                                     if not k.endswith("bijection.mask")}, strict=False)
-                d64 = d64.double().eval()
-                with torch.no_grad():
-                    inner64 = d64.module.density if dequant else d64
-                    xin = (x + noise).double() if dequant else x.double()
-                    out["elbo_0_fp64"] = inner64.elbo(xin, add_offdiagonal_metric_reg=True)["elbo"].numpy()
-            finally:
-                torch.set_default_dtype(torch.float32)
+            # fp64 reference evaluation of the headline call and its parts, and the fp32 reference's own sensitivity to a
+            # 1e-6 relative move of its latent (tolerance analysis: tests/test_gpu_round3.py computes its bounds from these)
+            out.update(fp64_reference(get_density, schema, sd, x, noise, dequant))
+            with torch.no_grad():
+                ld_p, off_p = perturbed_parts(head, z_low)
+            out.update(logdet_pert=ld_p.numpy(), l1_off_pert=off_p.numpy())
         meta = {"dataset": dataset, "overrides": over, "batch": B, "recipe_seed": 0, "recipe_gain": gain, "nested_keys": nested_keys,
                 "state_dict": {k: [list(v.shape), str(v.dtype)] for k, v in sd.items()},
                 "elbo_combos": ELBO_COMBOS, "cond_jtj_max": float(torch.linalg.cond(jtj).max())}

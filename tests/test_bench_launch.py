@@ -40,3 +40,27 @@ def test_rank_environment_is_honoured(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
     bench.main()
     assert called == {"rank": 4}
+
+
+def test_a_failing_rank_stops_its_siblings_and_a_deadline_bounds_the_launch(tmp_path):
+    """one rank dying before the rendezvous must not leave the others waiting for the backend's timeout, and a run
+    that never ends is stopped at --launch-timeout (exit code 124).  Stand-in rank scripts, no GPU."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    dying = tmp_path / "dying.py"
+    dying.write_text("import os, sys, time\n"
+                     "if os.environ['RANK'] == '1':\n"
+                     "    print('rank 1: cannot initialise', file=sys.stderr); sys.exit(3)\n"
+                     "time.sleep(600)\n")
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(bench.parse_args(["--gpus", "3"]), [], script=str(dying))
+    assert rc == 3 and time.monotonic() - t0 < 30
+    hanging = tmp_path / "hanging.py"
+    hanging.write_text("import time\ntime.sleep(600)\n")
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(bench.parse_args(["--gpus", "2", "--launch-timeout", "2"]), [], script=str(hanging))
+    assert rc == 124 and time.monotonic() - t0 < 30
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os\nif os.environ['RANK'] == '0':\n    print('{\"value\": 1}')\n")
+    assert bench.spawn_ranks(bench.parse_args(["--gpus", "2"]), [], script=str(ok)) == 0

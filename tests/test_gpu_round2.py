@@ -307,11 +307,21 @@ def test_bench_launches_two_ranks_from_a_bare_shell():
     """``python bench.py --gpus 2`` with no launcher around it: the parent spawns the ranks (gloo + one shared GPU here: a
     rehearsal of the RCCL launch on a one-GPU box), relays ONE JSON line, world size as the process group saw it."""
     line = _bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--batch", "32", "--steps", "1", "--warmup", "1",
-                  "--cpu-batch", "0")
+                  "--cpu-batch", "0", "--leg-steps", "1")
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
     assert line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
     assert line["value"] > 0 and "REHEARSAL" in line["data"]
-    assert "cpu_baseline" not in line and "f32_exact" not in line
+    assert "cpu_baseline" not in line and "f32_exact" not in line and "train" not in line
+    # round 3: the N > 1 line also carries BASELINE configs[3] (the global batch of 512 sharded over the ranks) and configs[4]
+    # (CIFAR d = 128, 32 samples per GPU), timed in the same process group
+    s3, c5 = line["strong_c3"], line["c5"]
+    for leg in (s3, c5):
+        for k in ("metric", "value", "unit", "ms_per_step", "steps", "per_gpu_batch", "global_batch", "ranks_seen", "scaling", "roofline"):
+            assert k in leg, k
+        assert leg["ranks_seen"] == 2 and leg["value"] > 0
+        assert abs(leg["value"] - leg["global_batch"] * leg["steps"] / (leg["ms_per_step"] * 1e-3 * leg["steps"])) / leg["value"] < 1e-6
+    assert s3["scaling"] == "strong" and s3["per_gpu_batch"] == 256 and s3["global_batch"] == 512 and "MNIST" in s3["metric"]
+    assert c5["scaling"] == "weak" and c5["per_gpu_batch"] == 32 and c5["global_batch"] == 64 and "CIFAR" in c5["metric"]
 
 
 @pytest.mark.parametrize("config", ["c1", "c2b"])

@@ -1,0 +1,266 @@
+"""Round-3 GPU tests: the low-rank backward of the train-mode Hutchinson objective, the diagonal metric term on a rectangular
+Hutchinson product, fp64-anchored parity bounds.  Every call goes through the C ABI of libcmf_amd.so."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import COND, SMALL, fp64_bound, golden_model, load_golden
+from test_gpu_parity import build, find_head, inner, rel
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# train-mode Hutchinson: gradients through the 2 S directions {u_s, eps_s} instead of all d Jacobian columns
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def _small_wide_latent_model(d, hidden=(8, 8), seed=3):
+    """A mini MNIST-shaped model with a latent dimension wide enough for the low-rank sweep to save column slots, and the
+    float64 oracle restatement of the same weights (no reference vectors needed: the oracle differentiates itself)."""
+    import cmf_amd
+    from cmf_amd.recipe import fill_state_dict
+    from oracle import cmf_oracle as O
+    cfg = cmf_amd.get_config("mnist", latent_dimension=d, g_hidden_channels=list(hidden), log_jacobian_method="hutch_with_cg")
+    schema = cmf_amd.get_schema(cfg)
+    shape = cmf_amd.DATA_SHAPES["mnist"]
+    dens = cmf_amd.get_density(schema, torch.zeros(1, *shape))
+    sd = fill_state_dict(dens.state_dict(), seed=seed)
+    dens.load_state_dict(sd, strict=True)
+    ops = O.compile_schema(schema, shape)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    return cfg, dens.cuda().eval(), ops, sd64
+
+
+@pytest.mark.parametrize("nc_quantum,hidden,diag", [(16, (8, 8), False), (32, (64,), False), (16, (8, 8), True)])
+def test_lowrank_hutchinson_gradients_match_oracle_autograd(nc_quantum, hidden, diag):
+    """VERDICT r2 missing #1.  The reference builds its graph only through ``w = J^T J eps`` for the S probes, ``u`` detached
+    (non_square.py:241-256); here the kept sweep carries V = [u | eps (| e_k)] and the cotangent of P = J V is P (C + C^T).
+    Parameter gradients = torch.autograd through the float64 oracle with u = solve(J^T J, eps).detach(), with and without the
+    diagonal metric term on the RECTANGULAR (d, S) product (torch.diagonal, non_square.py:87-92: min(d, S) entries)."""
+    from oracle import cmf_oracle as O
+    d, S, B = 40, 2, 3
+    cfg, dens, ops, sd = _small_wide_latent_model(d, hidden)       # 64 hidden channels: the split-precision conv / wgrad kernels
+    head = find_head(dens)
+    head.num_hutchinson_samples, head.max_cg_iterations, head.cg_tolerance, head.HUTCH_LOWRANK_NC = S, 8 * d, 1e-8, nc_quantum
+    assert head._hutch_lowrank_columns(diag, False) == (2 * S + (S if diag else 0), nc_quantum)
+    assert head._hutch_lowrank_columns(diag, True) is None                       # the off-diagonal term needs every column
+    named = dict(dens.named_parameters())
+    gen = torch.Generator().manual_seed(11)
+    z_low = 0.5 * torch.randn(B, d, generator=gen)
+    eps, a, c = torch.randn(B, d, S, generator=gen), torch.randn(B, generator=gen), torch.randn(B, generator=gen)
+    keys = [k for k, v in sd.items() if v.is_floating_point() and k in named]
+    sd64 = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    pre, hd, flow_ops, base, prior_ops = O.split_ops(ops)
+    zd = z_low.double().requires_grad_(True)
+    jtj, xh, J = O.jtj_batched(sd64, flow_ops, base, zd)
+    w = torch.bmm(jtj, eps.double())
+    u = torch.linalg.solve(jtj, eps.double()).detach()
+    value = (u * w).sum(1).mean(1)
+    l1d = torch.diagonal(w, dim1=-2, dim2=-1).abs().sum(1)
+    obj = (a.double() * value).sum() + ((c.double() * l1d).sum() if diag else 0.0)
+    want = torch.autograd.grad(obj, [sd64[k] for k in keys] + [zd], allow_unused=True)
+    st = head.head_terms_forward(z_low.cuda(), tangents=True, hutch_eps=eps.cuda(), add_diag=diag)
+    assert st["hutch"]["lowrank"] is not None and st["T"].nc == nc_quantum
+    assert rel(st["hutch"]["value"], value) < 1e-4 and rel(st["hutch"]["u"], u) < 1e-3
+    if diag:
+        assert rel(st["hutch"]["l1_diag"], l1d) < 1e-4 and st["hutch"]["l1_off"] is None
+    out = head.head_terms_backward(z_low.cuda(), None, g_logdet=a.cuda(), g_l1diag=c.cuda() if diag else None, state=st)
+    errs = {}
+    for k, wv in zip(keys, want[:-1]):
+        if wv is not None and float(wv.abs().max()) > 0:
+            errs[k] = rel(out["grads"][named[k]], wv.reshape(named[k].shape))
+    worst = max(errs, key=errs.get)
+    print(f"low-rank nc={nc_quantum} diag={diag}: {len(errs)} tensors, worst {errs[worst]:.1e} ({worst}), dz {rel(out['dz_low'], want[-1]):.1e}")
+    assert len(errs) >= 40 and errs[worst] < 2e-3, (worst, errs[worst])
+    assert rel(out["dz_low"], want[-1]) < 2e-3
+    # the d-column backward (hutch_lowrank = False) gives the same gradients from the same probes
+    head.hutch_lowrank = False
+    st2 = head.head_terms_forward(z_low.cuda(), tangents=True, hutch_eps=eps.cuda(), add_diag=diag)
+    assert st2["hutch"].get("lowrank") is None and st2["T"].nc == 48
+    out2 = head.head_terms_backward(z_low.cuda(), None, g_logdet=a.cuda(), g_l1diag=c.cuda() if diag else None, state=st2)
+    for k in errs:
+        assert rel(out["grads"][named[k]], out2["grads"][named[k]]) < 2e-4, k
+    assert rel(out["dz_low"], out2["dz_low"]) < 2e-4
+
+
+def test_lowrank_hutchinson_equals_the_d_column_backward_on_the_full_size_cifar_model():
+    """The same equality on BASELINE configs[4]'s own model (``c5_cifar_full``: D = 3072, d = 128, S = 4 -- 8 directions in 32
+    column slots against 128) through ``loss.backward()``, 32 samples (the bit-mask / grouped-activation training path), and the
+    memory the step needs: the d-column backward kept 17 x 128-column hidden tangents per coupler (85.8 GiB at 32 samples)."""
+    g, meta, cfg, dens = build("c5_cifar_full")                   # the fixture pins the eval path: cholesky in its overrides
+    head = find_head(dens)
+    head.log_jacobian_method = "hutch_with_cg"                    # BASELINE configs[4]'s training method (cifar10 default)
+    assert head.num_hutchinson_samples == 4
+    core = inner(dens, True)
+    dens.train()
+    B = 32
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randint(0, 256, (B, 3, 32, 32), generator=gen).float() + torch.rand(B, 3, 32, 32, generator=gen)).cuda()
+    grads, peaks, elbos = {}, {}, {}
+    for mode in ("lowrank", "full"):
+        head.hutch_lowrank = None if mode == "lowrank" else False
+        dens.zero_grad()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        torch.manual_seed(123)                                                    # the same probes in both runs
+        with torch.enable_grad():
+            out = core.elbo(x.clone(), add_reconstruction=True)["elbo"]
+            (-out.mean()).backward()
+        torch.cuda.synchronize()
+        peaks[mode] = torch.cuda.max_memory_allocated() / 2 ** 30
+        elbos[mode] = out.detach().clone()
+        assert (head.last_hutchinson.get("lowrank") is not None) == (mode == "lowrank")
+        grads[mode] = {k: p.grad.detach().clone() for k, p in dens.named_parameters() if p.grad is not None}
+    assert rel(elbos["lowrank"], elbos["full"]) < 1e-5
+    errs = {k: rel(grads["lowrank"][k], grads["full"][k]) for k in grads["full"] if float(grads["full"][k].abs().max()) > 0}
+    worst = max(errs, key=errs.get)
+    print(f"C5 full size, 32 samples: {len(errs)} tensors, worst {errs[worst]:.1e} ({worst}); peak memory {peaks}")
+    assert len(errs) >= 300 and errs[worst] < 2e-3, (worst, errs[worst])
+    assert peaks["lowrank"] < 0.35 * peaks["full"]
+
+
+def test_diagonal_metric_term_on_a_rectangular_hutchinson_product():
+    """``add_diagonal_metric_reg`` with S != d is valid in the reference (torch.diagonal of the (B, d, S) product,
+    non_square.py:87-92); only the off-diagonal variant needs S == d (:98)."""
+    from oracle import cmf_oracle as O
+    g, meta, cfg, dens = build("mini_mnist")
+    head = find_head(dens)
+    d = head.program.d
+    head.log_jacobian_method, head.num_hutchinson_samples, head.max_cg_iterations, head.cg_tolerance = "hutch_with_cg", d - 1, 4 * d, 1e-7
+    dens.train()
+    x = (g["x"] + g["noise"])[:3].float().cuda()
+    with torch.no_grad():
+        torch.manual_seed(5)
+        got = inner(dens, True).elbo(x.clone(), metric_wt=0.7, add_diagonal_metric_reg=True)["elbo"]
+        h = head.last_hutchinson
+        torch.manual_seed(5)
+        base = inner(dens, True).elbo(x.clone(), metric_wt=0.7)["elbo"]
+    l1 = torch.diagonal(h["w"].cpu().double(), dim1=-2, dim2=-1).abs().sum(1, keepdim=True)
+    assert h["w"].shape == (3, d, d - 1) and rel(got, base.cpu().double() - 0.7 * l1) < 1e-5
+    with pytest.raises(ValueError, match="num_hutchinson_samples"):
+        inner(dens, True).elbo(x.clone(), add_offdiagonal_metric_reg=True)
+    with torch.enable_grad():                                                     # and it trains
+        dens.zero_grad()
+        (-inner(dens, True).elbo(x.clone(), metric_wt=0.7, add_diagonal_metric_reg=True)["elbo"].mean()).backward()
+    gn = torch.stack([p.grad.norm() for p in dens.parameters() if p.grad is not None])
+    assert torch.isfinite(gn).all() and float(gn.max()) > 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fp64-anchored, per-sample parity bounds computed from reference-generated data (missing #4, weak #1 / #2)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def _check_against_fp64(tag, got, fp64, ref32, pert=None, extra=None):
+    bound, yard = fp64_bound(fp64, ref32, pert, extra)
+    err = (got.detach().cpu().double().reshape(-1) - fp64.double().reshape(-1)).abs()
+    worst = int((err / bound).argmax())
+    assert bool((err <= bound).all()), (tag, f"sample {worst}: |HIP - fp64| {float(err[worst]):.3e} > bound {float(bound[worst]):.3e} "
+                                             f"(fp64 {float(fp64.reshape(-1)[worst]):.6e}, reference yardstick {float(yard[worst]):.3e})")
+    return float((err / fp64.double().reshape(-1).abs().clamp_min(1e-30)).max())
+
+
+@pytest.mark.parametrize("name", SMALL + COND)
+def test_hip_path_against_the_float64_reference_per_sample(name):
+    """"vs imported-reference fixtures *and* vs an fp64 evaluation".  Per SAMPLE (not max-norm over the batch):
+    |HIP - fp64| <= max(1e-4 |fp64|, 3 x |reference_fp32 - fp64|) for the elbo of the headline call, log det J^T J and the g_ij
+    loss, where the float32 reference's distance from fp64 includes its own movement under a 1e-6 relative move of its latent
+    (the relu-kink yardstick).  All four quantities come from the reference itself (oracle/make_golden.py)."""
+    g, meta, cfg, dens = build(name)
+    assert "logdet_fp64" in g and "logdet_pert" in g, "fixture predates round 3: regenerate with oracle/make_golden.py"
+    head = find_head(dens)
+    dequant = "noise" in g
+    x = (g["x"] + g["noise"]) if dequant else g["x"]
+    with torch.no_grad():
+        out = inner(dens, dequant).elbo(x.cuda(), add_offdiagonal_metric_reg=True)
+    gr = head.last_gram
+    ref_off = g["jtj"].abs().sum((1, 2)) - torch.diagonal(g["jtj"], dim1=1, dim2=2).abs().sum(1)
+    e_ld = _check_against_fp64("logdet", gr.logdet, g["logdet_fp64"], g["logdet"], g["logdet_pert"])
+    e_off = _check_against_fp64("g_ij", gr.l1_off, g["l1_off_fp64"], ref_off, g["l1_off_pert"])
+    # elbo = low - logdet / 2 - lambda rec - l1: its kink yardstick is the parts' movement
+    ld0, off0 = g["logdet"].double().reshape(-1), ref_off.double()
+    move = 0.5 * (g["logdet_pert"].double() - ld0).abs().max(0).values + (g["l1_off_pert"].double() - off0).abs().max(0).values
+    e_el = _check_against_fp64("elbo", out["elbo"], g["elbo_0_fp64"], g["elbo_0"], None, extra=move)
+    print(f"{name}: per-sample relative error vs fp64: elbo {e_el:.1e} logdet {e_ld:.1e} g_ij {e_off:.1e}")
+
+
+def test_full_size_statistics_against_the_float64_reference():
+    """The 32 fresh MNIST-sized inputs of the full d = 64 model (BASELINE configs[2]'s model), now against the REFERENCE in
+    float32 and float64 (``c3_mnist_stats32``, generated once in the build container): per-sample computed bounds as above, and
+    the batch-mean / median agreement with the float32 reference that the 1e-4 tolerance of SURVEY 8d is about.  No typed-in
+    per-sample constant: a sample near a relu kink is admitted exactly as far as the reference's own yardstick says."""
+    import cmf_amd
+    from cmf_amd.recipe import fill_state_dict
+    g, meta = load_golden("c3_mnist_stats32")
+    cfg = cmf_amd.get_config("mnist", **meta["overrides"])
+    x = g["x"].float() + g["noise"]
+    dens = cmf_amd.get_density(cmf_amd.get_schema(cfg), x[:4])
+    dens.load_state_dict(fill_state_dict(dens.state_dict(), seed=meta["recipe_seed"]), strict=True)
+    dens = dens.cuda().eval()
+    with torch.no_grad():
+        got = inner(dens, True).elbo(x.cuda(), add_offdiagonal_metric_reg=True)
+    gram = find_head(dens).last_gram
+    ld0, off0 = g["logdet"].double().reshape(-1), g["l1_off"].double().reshape(-1)
+    move = 0.5 * (g["logdet_pert"].double() - ld0).abs().max(0).values + (g["l1_off_pert"].double() - off0).abs().max(0).values
+    worst = {"logdet": _check_against_fp64("logdet", gram.logdet, g["logdet_fp64"], g["logdet"], g["logdet_pert"]),
+             "g_ij": _check_against_fp64("g_ij", gram.l1_off, g["l1_off_fp64"], g["l1_off"], g["l1_off_pert"]),
+             "elbo": _check_against_fp64("elbo", got["elbo"], g["elbo_0_fp64"], g["elbo_0"], None, extra=move)}
+    per = lambda a, b: ((a.cpu().double().flatten() - b.double().flatten()).abs() / b.double().flatten().abs())
+    mean_rel = lambda a, b: abs(float(a.cpu().double().mean() - b.double().mean())) / abs(float(b.double().mean()))
+    for name, a, b32, b64 in (("elbo", got["elbo"], g["elbo_0"], g["elbo_0_fp64"]), ("logdet", gram.logdet, g["logdet"], g["logdet_fp64"]),
+                              ("g_ij", gram.l1_off, g["l1_off"], g["l1_off_fp64"])):
+        assert mean_rel(a, b32) < 2e-5 and mean_rel(a, b64) < 2e-5, (name, "batch mean", mean_rel(a, b32), mean_rel(a, b64))
+        assert float(per(a, b32).median()) < 5e-6 and float(per(a, b64).median()) < 5e-6, (name, "median")
+        # the float32 reference is no closer to float64 than this path (3 x, medians)
+        assert float(per(a, b64).median()) <= 3 * float(per(b32, b64).median()) + 1e-7, name
+    print("full-size MNIST model, 32 samples, worst per-sample relative error vs fp64:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# threading contract: re-entrant ops on the calling thread's current stream, no static scratch
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def test_two_threads_two_streams_one_device():
+    """``nn.DataParallel`` drives one thread per GPU (wrapper.py:52-68); a one-GPU box cannot run
+    test_two_devices_one_process, so the re-entrancy half of that contract is exercised here: two Python threads, each on its
+    own HIP stream of cuda:0, evaluate and train different batches concurrently through the same library.  Results equal the
+    sequential ones bit for bit (no shared scratch buffers, workspaces keyed by stream, every launch on the caller's stream)."""
+    import threading
+    g, meta, cfg, dens = build("mini_mnist")
+    core = inner(dens, True)
+    gen = torch.Generator().manual_seed(3)
+    xs = [(torch.randint(0, 256, (8, 1, 28, 28), generator=gen).float() + torch.rand(8, 1, 28, 28, generator=gen)).cuda() for _ in range(2)]
+    kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=True)
+
+    def evaluate(x):
+        with torch.no_grad():
+            e = core.elbo(x.clone(), **kw)["elbo"].clone()
+        head = find_head(dens)
+        st = head.head_terms_forward(head.program.encode(x.clone())[0], tangents=True)
+        out = head.head_terms_backward(None, x, g_logdet=torch.ones(x.shape[0], device="cuda"), state=st)
+        gsum = torch.stack([v.double().abs().sum() for v in out["grads"].values()]).sum()
+        return e, gsum
+
+    want = [evaluate(x) for x in xs]                      # sequential, default stream (also warms the weight packs)
+    torch.cuda.synchronize()
+    got, errs = [None, None], []
+
+    def worker(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    got[i] = evaluate(xs[i])
+            s.synchronize()
+        except Exception as e:                            # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for i in range(2):
+        assert torch.equal(got[i][0], want[i][0]), i
+        assert abs(float(got[i][1] - want[i][1])) <= 1e-9 * abs(float(want[i][1])), i

@@ -94,6 +94,51 @@ def test_fp64_oracle_vs_fp64_reference(name):
     assert rel(r["elbo"], g["elbo_0_fp64"]) < 1e-12
 
 
+@pytest.mark.parametrize("name", ["c1_sphere", "c2b_hepmass_cond1e3", "mini_mnist", "mini_cifar_cond1e2"])
+def test_fp64_oracle_parts_vs_fp64_reference(name):
+    """Round 3: the float64 reference's log det J^T J, g_ij / g_kk sums and low-dimensional elbo (``*_fp64`` keys) against the
+    float64 oracle, and the float32 reference's own movement under the +-1e-6 latent perturbation (``*_pert``) against the
+    float32 oracle at the same perturbed latents -- the yardsticks tests/test_gpu_round3.py builds its per-sample bounds from."""
+    g, meta = load_golden(name)
+    cfg, schema, x_shape, ops, sd64 = golden_model(meta, dtype=torch.float64)
+    noise = g.get("noise")
+    x = g["x"].double() if noise is None else (g["x"] + noise).double()
+    with torch.no_grad():
+        r = O.elbo(sd64, ops, x, add_offdiagonal_metric_reg=True, noise=None if noise is None else torch.zeros_like(x), return_parts=True)
+    p = r["parts"]
+    assert rel(p["logdet"].reshape(-1), g["logdet_fp64"].reshape(-1)) < 1e-11
+    assert rel(p["l1"].reshape(-1), g["l1_off_fp64"].reshape(-1)) < 1e-11
+    assert rel(p["low_dim_elbo"].reshape(-1), g["low_dim_elbo_fp64"].reshape(-1)) < 1e-11
+    # perturbed latents through the float32 oracle: same jumps as the float32 reference
+    _, _, _, ops32, sd32 = golden_model(meta)
+    pre, hd, flow_ops, base, prior_ops = O.split_ops(ops32)
+    with torch.no_grad():
+        for i, sgn in enumerate((1.0, -1.0)):
+            jtj, _, _ = O.jtj_batched(sd32, flow_ops, base, g["z_low"] * (1.0 + sgn * 1e-6))
+            logdet, _, _ = O.cholesky_logdet(jtj)
+            off = jtj.abs().sum((1, 2)) - torch.diagonal(jtj, dim1=1, dim2=2).abs().sum(1)
+            assert rel(logdet.reshape(-1), g["logdet_pert"][i]) < 1e-4 and rel(off, g["l1_off_pert"][i]) < 1e-4
+
+
+def test_full_size_statistics_fixture_is_the_reference():
+    """``c3_mnist_stats32``: 32 full-size MNIST inputs through the reference in float32 and float64.  The oracle reproduces the
+    first two samples (a few seconds of CPU), and the float32 reference sits within 1e-4 of float64 per sample except where its
+    own 1e-6 perturbation yardstick says a relu kink is near."""
+    g, meta = load_golden("c3_mnist_stats32")
+    assert g["x"].dtype == torch.uint8 and g["x"].shape == (32, 1, 28, 28) and meta["input_seed"] == 2024
+    cfg, schema, x_shape, ops, sd = golden_model(meta)
+    x = (g["x"].float() + g["noise"])[:2]
+    with torch.no_grad():
+        r = O.elbo(sd, ops, x, add_offdiagonal_metric_reg=True, noise=torch.zeros_like(x), return_parts=True)
+    assert rel(r["elbo"], g["elbo_0"][:2]) < 1e-5 and rel(r["parts"]["logdet"].reshape(-1), g["logdet"].reshape(-1)[:2]) < 1e-5
+    for key, ref in (("logdet", g["logdet"].reshape(-1)), ("l1_off", g["l1_off"].reshape(-1))):
+        f64 = g[f"{key}_fp64"].double().reshape(-1)
+        err = (ref.double() - f64).abs() / f64.abs()
+        move = ((g[f"{key}_pert"].double() - ref.double()).abs().max(0).values / f64.abs())
+        assert bool((err < torch.maximum(torch.tensor(1e-4, dtype=torch.float64), 3 * move)).all()), key
+        assert float(err.median()) < 5e-6
+
+
 def test_conditioning_of_the_fixtures_is_what_the_names_say():
     """cond(J^T J) as the REFERENCE's matrices have it (meta written by make_golden.py from the reference's own J^T J)."""
     want = {"mini_mnist_cond1e2": (50, 400), "mini_mnist_cond1e3": (400, 5e3), "mini_cifar_cond1e2": (50, 400),

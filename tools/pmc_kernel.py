@@ -34,6 +34,7 @@ ap.add_argument("--kernel", action="append", required=True)
 ap.add_argument("--out", required=True)
 ap.add_argument("--note", default="")
 ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--source", default=None, help="kernel source file: its SHA-256 (first 16 hex digits) is stamped into the summary")
 a = ap.parse_args()
 acc = defaultdict(lambda: defaultdict(list))
 for d in a.dirs:
@@ -42,6 +43,10 @@ for d in a.dirs:
             if sub in k:
                 acc[sub][c].append(v)
 out = {"command": a.note, "batch": a.batch, "kernels": {}}
+if a.source:
+    import hashlib
+    out["kernel_source"] = os.path.relpath(a.source)
+    out["kernel_source_sha16"] = hashlib.sha256(open(a.source, "rb").read()).hexdigest()[:16]
 for sub, cs in acc.items():
     e = {"launches": max(len(v) for v in cs.values()), "counters_avg_per_launch": {c: sum(v) / len(v) for c, v in sorted(cs.items())}}
     m = e["counters_avg_per_launch"]
