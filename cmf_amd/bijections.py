@@ -166,7 +166,7 @@ class AffineCouplingBijection(Bijection):
         E.net_cotangent(self.net, YC, self.view(dev), acts, Ct)
 
     # training: decode keeping what the backward needs, and the backward of that step ------------
-    def decode_train_(self, z, T, keep=True):
+    def decode_train_(self, z, T, keep=True, nc_hint=None):
         """``decode_`` on (z, T) in place; returns the context ``decode_backward_`` consumes: the layer input, the network's
         outputs and activations and, with a tangent stack (``T`` not None), every layer's input tangent, the modified tangent
         rows before the update and the network's raw tangent.  ``keep=False`` (recomputation): only the layer's inputs (z and a
@@ -177,7 +177,10 @@ class AffineCouplingBijection(Bijection):
             return ctx
         view, maps = self.view(z.device), self.maps(z.device)
         zb = z.clone()
-        y, g, acts = E.net_primal(self.net, z, view, need_acts=E.train_acts_mode(self.net, view, z.shape[0], T))
+        # ``nc_hint``: primal-only pass (T is None) whose activations a later tangent sweep with that many column slots reads
+        import types
+        acts_for = T if T is not None or nc_hint is None else types.SimpleNamespace(nc=int(nc_hint))
+        y, g, acts = E.net_primal(self.net, z, view, need_acts=E.train_acts_mode(self.net, view, z.shape[0], acts_for))
         saved = V = YT = None
         if T is not None:
             saved = []
@@ -186,6 +189,19 @@ class AffineCouplingBijection(Bijection):
             E.acl_tangent(T, YT, z, y, g, maps)
         E.acl_primal(z, y, maps, decode=True)
         return zb, y, g, acts, saved, V, YT
+
+    def decode_tangent_from_ctx_(self, ctx, T, save=False):
+        """The tangent half of ``decode_train_`` on a context whose primal half is already there (``decode_train_(z, None)``):
+        pushes ``T`` through the layer in place.  ``save=False``: nothing is kept (the d-column sweep that only feeds the Gram
+        matrix); ``save=True``: returns the context ``decode_backward_`` consumes for THIS stack (the layer's primal state is
+        shared, not recomputed) -- the low-rank Hutchinson backward runs both on one primal decode."""
+        zb, y, g, acts = ctx[:4]
+        view, maps = self.view(zb.device), self.maps(zb.device)
+        saved = [] if save else None
+        YT = E.net_tangent(self.net, T, view, acts, save=saved)
+        V = E.modified_rows(T, maps) if save else None
+        E.acl_tangent(T, YT, zb, y, g, maps)                 # zb: the layer input, i.e. z BEFORE the primal update
+        return (zb, y, g, acts, saved, V, YT) if save else None
 
     def decode_backward_(self, Ct, dx, ctx, grads):
         """Backward of ``decode_train_``: ``Ct`` (cotangent of the tangent stack, or None) and ``dx`` (cotangent of the primal
@@ -338,6 +354,10 @@ class _ReshapingBijection(Bijection):
             T = E.gather_tangent(T, self._maps.get("z2x", z.device), self.n)
         return x, T
 
+    def decode_tangent(self, T):
+        """``decode`` on a tangent stack alone (the primal tensor went through it in an earlier pass)."""
+        return E.gather_tangent(T, self._maps.get("z2x", T.data.device), self.n)
+
     def decode_vjp(self, Ct):
         """Adjoint of ``decode`` on a cotangent stack: the inverse index map."""
         return E.gather_tangent(Ct, self._maps.get("x2z", Ct.data.device), self.n)
@@ -370,6 +390,9 @@ class ViewBijection(_ReshapingBijection):
 
     def decode(self, z, T=None):
         return z.view(z.shape[0], *self.x_shape), T
+
+    def decode_tangent(self, T):
+        return T
 
     def decode_vjp(self, Ct):
         return Ct

@@ -247,10 +247,20 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     // `s_nop 4` opens every load statement: descriptor / soffset SGPRs may have just been written by SALU code.
     auto prefetch_w = [&]() {
       const int wco = wcur_ch * C::W_CHUNK_BYTES;
+      // K-step 2 of a slab (the four-octet centre K-step) is consumed in every FOURTH chunk only: in the other chunks its two
+      // 4-KiB items (hi, lo) are fetched through a zero-record descriptor -- same instruction count for the hand-counted waits,
+      // no L2 / fabric traffic -- and not written to LDS (commit below): 1/3 of the weight bytes in 3 of 4 chunks (round 3: +0.6 ..
+      // 1.3 % on the 64 -> 64 launches, results bit-identical)
+      i32x4 wrs2 = wrs;
+      wrs2[2] = __builtin_amdgcn_readfirstlane((COT != 4 || (wcur_ch & 3) == 3) ? -1 : 0);
 #pragma unroll
       for (int it = 0; it < C::NWIT; ++it) {
         const int vo = woff[COT == 4 ? 0 : it % NWOFF];
         const int so = COT == 4 ? wco + it * 4096 : wco;
+        if (COT == 4 && it % 3 == 2) {
+          asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(wreg[it]) : "v"(vo), "s"(wrs2), "s"(so) : "memory");
+          continue;
+        }
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(wreg[it]) : "v"(vo), "s"(wrs), "s"(so) : "memory");
       }
       if (++wcur_ch == nchunks) {
@@ -342,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wreg[0]), "+v"(wreg[1]), "+v"(wreg[2]) : "n"(N));
     };
 
+    int com_ch = 0;                                                // channel chunk (within its item) of the next commit
     auto commit = [&](Regs& r, int stage) {
 #ifdef CMF_DBG_NOCOMMIT
 #pragma unroll
@@ -405,9 +416,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #endif
       }
       wait_w();
+      const bool wquad = COT != 4 || (com_ch & 3) == 3;           // the chunk being committed runs the centre K-step
+      com_ch = com_ch + 1 == nchunks ? 0 : com_ch + 1;
 #pragma unroll
       for (int it = 0; it < C::NWIT; ++it) {
         const int i = lt + 256 * it;
+        if (COT == 4 && it % 3 == 2 && !wquad) continue;          // wave-uniform
         if (i < C::NW_ITEMS) {
           const int rest = i & 63, t = i >> 6;
           const int cot = t % COT, s = (t / COT) % 3, hl = t / (3 * COT);
@@ -704,6 +718,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     // non-QUAD chunk: park this octet's centre pixels in ring slot `ring_slot`: the two waves of a tile row split hi / lo,
     // 14 pixel rows of 256 B = 224 sixteen-byte units per wave
     u32x4 cp[4];
+#ifndef CMF_DBG_NORING
     if (!QUAD) {
       const unsigned char* src = (cohalf ? Xl : Xh) + cpix * 256;
 #pragma unroll
@@ -712,6 +727,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         if (u < PW * 16) cp[k] = *reinterpret_cast<const u32x4*>(src + u * 16 + ((u >> 4) / C::TW) * (C::TWH - C::TW) * 256);
       }
     }
+#endif
 #pragma unroll
     for (int t = 0; t < BD - 1; ++t) load_b(t);
     __builtin_amdgcn_sched_barrier(0);
@@ -719,6 +735,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     for (int t = 0; t < NSTEP; ++t) {
       const int s = t % KS, p = t / KS;
       if (t + BD - 1 < NSTEP) load_b(t + BD - 1);
+#ifndef CMF_DBG_NORING
       if (!QUAD && t == 2) {                                       // the copy's reads have long landed
         unsigned char* dst = smem + 2 * C::BUF_BYTES + ring_slot * C::RING_SLOT + (cohalf ? C::RING_HALF : 0) + wrow * C::TW * 256;
 #pragma unroll
@@ -727,17 +744,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
           if (u < PW * 16) *reinterpret_cast<u32x4*>(dst + u * 16) = cp[k];
         }
       }
+#endif
       if (FIRST && s == 0) wait_res(p, false);
-#ifdef CMF_DBG_MFMAORD
-      // experiment: product-major order -- the X fragment (srcA) stays on the operand bus for CW consecutive MFMAs and
-      // consecutive MFMAs never share an accumulator
-#pragma unroll
-      for (int c = 0; c < CW; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], al[s][c], acc[p][c], 0, 0, 0);
-#pragma unroll
-      for (int c = 0; c < CW; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
-#pragma unroll
-      for (int c = 0; c < CW; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
-#else
 #pragma unroll
       for (int c = 0; c < CW; ++c) {
         // D[row = Jacobian column][col = output channel] = X-fragment (as A) x W-fragment (as B): each lane then
@@ -746,7 +754,6 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
         acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
       }
-#endif
       if (LAST && s == KS - 1) {
         store_pixel(cur, p);
         init_pixel(nxt, nxt_rrs, p);

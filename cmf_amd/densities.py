@@ -472,7 +472,7 @@ class FlowProgram:
         return z, out.to_dense(S).contiguous()
 
     # -- training: decode with saved state, and its backward -------------------------------
-    def decode_train(self, z_low, tangents=True, keep=True, eps=None, nc=None):
+    def decode_train(self, z_low, tangents=True, keep=True, eps=None, nc=None, nc_hint=None):
         """``decode(z_low, tangents)`` keeping every coupling layer's context (``keep=False``: only its inputs, the rest is
         recomputed layer by layer in ``decode_backward``); returns (x_hat, T, ctx).  ``eps`` (B, d, n): the sweep carries the n
         directions J eps instead of the d Jacobian columns (low-rank Hutchinson backward), in ``nc`` >= n column slots."""
@@ -487,7 +487,7 @@ class FlowProgram:
         ctx = []
         for m in reversed(self.layers):
             if isinstance(m, AffineCouplingBijection):
-                ctx.append(m.decode_train_(z, T, keep))
+                ctx.append(m.decode_train_(z, T, keep, nc_hint=nc_hint))
             elif isinstance(m, SplitDensity):
                 n = z[0].numel()
                 idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),
@@ -499,6 +499,29 @@ class FlowProgram:
                 z, T = m.decode(z, T)
                 ctx.append(None)
         return z, T, ctx
+
+    def decode_tangents_from_ctx(self, ctx, eps=None, nc=None, save=False):
+        """A tangent sweep over the PRIMAL contexts of ``decode_train(z_low, tangents=False)``: returns (T, ctx') where ctx' is
+        the context list ``decode_backward`` consumes when ``save`` (else None).  Layers are walked like ``decode_train``."""
+        dev = self.tail.permutation.device
+        B = next(c[0].shape[0] for c in ctx if isinstance(c, tuple))
+        N = int(np.prod(self.tail.x_shape))
+        ncols = self.d if eps is None else eps.shape[2]
+        nc = E.ceil16(ncols) if nc is None else int(nc)
+        T = E.seed_tangent(B, N, nc, self.layout, self.tail.scatter_index(dev), self.d, dev, eps=eps)
+        out = []
+        for m, c in zip(reversed(self.layers), ctx):
+            if isinstance(m, AffineCouplingBijection):
+                out.append(m.decode_tangent_from_ctx_(c, T, save))
+            elif isinstance(m, SplitDensity):
+                n = c
+                idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev), torch.full((n,), -1, dtype=torch.int32, device=dev)))
+                T = E.gather_tangent(T, idx, 2 * n)
+                out.append(n)
+            else:
+                T = m.decode_tangent(T)
+                out.append(None)
+        return T, (out if save else None)
 
     def decode_backward(self, ctx, Ct, dx, grads):
         """Backward of ``decode_train``: ``Ct`` = cotangent of the Jacobian stack at the head (e.g. ``engine.gram_backward``),
@@ -902,7 +925,11 @@ class NonSquareHeadDensity(Density):
             low = self._hutch_lowrank_columns(add_diag, add_off) if (tangents and hutch_eps is not None) else None
             if low is not None:
                 prog, d, S = self.program, self.program.d, hutch_eps.shape[2]
-                _, T = prog.decode(z_low.detach(), tangents=True)                 # all d columns, nothing kept
+                # ONE primal decode keeping every layer's state; all d columns over it with nothing kept (the Gram matrix) ...
+                n, nc = low
+                hint = 32 if (nc % 32 == 0 and E.ceil16(d) % 32 == 0) else 16       # what both sweeps' kernels can read
+                x_hat, _, pctx = prog.decode_train(z_low.detach(), tangents=False, nc_hint=hint)
+                T, _ = prog.decode_tangents_from_ctx(pctx)
                 gr = E.gram_cholesky(T, d, 1)                                       # the Hutchinson branch never factorises
                 del T
                 self.last_gram = gr
@@ -911,14 +938,18 @@ class NonSquareHeadDensity(Density):
                 if add_diag:
                     hutch["l1_off"], hutch["l1_diag"] = E.hutch_metric(w)
                 self.last_hutchinson = hutch
-                n, nc = low
                 V = torch.zeros(z_low.shape[0], d, n, dtype=torch.float32, device=z_low.device)
                 V[:, :, :S] = u
                 V[:, :, S:2 * S] = hutch_eps
                 if add_diag:
                     k = torch.arange(min(d, S), device=z_low.device)
                     V[:, k, 2 * S + k] = 1.0
-                x_hat, TV, ctx = prog.decode_train(z_low.detach(), True, keep, eps=V, nc=nc)
+                # ... then the n directions over the SAME primal state, this sweep kept for the backward pass
+                if keep:
+                    TV, ctx = prog.decode_tangents_from_ctx(pctx, eps=V, nc=nc, save=True)
+                else:                                                               # recomputation per layer: inputs only
+                    del pctx
+                    x_hat, TV, ctx = prog.decode_train(z_low.detach(), True, keep, eps=V, nc=nc)
                 return {"x_hat": x_hat, "T": TV, "ctx": ctx, "gram": gr, "hutch": hutch}
             x_hat, T, ctx = self.program.decode_train(z_low.detach(), tangents, keep)
             gr = hutch = None

@@ -21,6 +21,7 @@ from cmf_amd import engine as E
 E.TANGENT_PRECISION = args.precision
 B, H, nc, ch = args.B, args.hw, args.nc, 64
 HW = H * H
+torch.manual_seed(0)
 x = torch.randn(B, ch, H, H, nc, device="cuda"); prim = torch.randn(B, ch, H, H, device="cuda")
 res = torch.randn(B, ch, H, H, nc, device="cuda") if args.res else None
 y = torch.randn(B, ch, H, H, nc, device="cuda") if args.wgrad else torch.empty(B, ch, H, H, nc, device="cuda")
@@ -46,5 +47,6 @@ for _ in range(args.iters): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.iters
 fl = 2.0 * ch * ch * 9 * HW * nc * B
+chk = (dw if args.wgrad else y).double()
 print(f"{os.path.basename(args.lib or 'libcmf_amd.so'):28s} B={B} {H}x{H} res={args.res} {'wgrad f32' if args.wgrad else args.precision} {args.layout}: {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s  "
-      f"{4.0*HW*nc*B*ch*(2+args.res)/ms/1e6:7.1f} GB/s")
+      f"{4.0*HW*nc*B*ch*(2+args.res)/ms/1e6:7.1f} GB/s  checksum {float(chk.sum()):.9e} {float(chk.abs().sum()):.9e}")

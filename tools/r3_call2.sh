@@ -2,11 +2,12 @@
 # round 3, GPU call 2: phase stamps of the dominant kernel, the new tests, the default bench line with its legs, C5 training variants
 out=gpurun_out/r3c2; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-timeout -k 10 120 python tools/read_stamps.py 1 > $out/stamps.txt 2>&1 || { tail -5 $out/stamps.txt; exit 1; }
-for cfg in "--hw 28 --precision f32" "--hw 14 --precision f32" "--hw 28 --precision bf16x3" "--hw 14 --precision bf16x3"; do
-  timeout -k 10 120 python tools/bench_conv.py --B 32 --nc 16 --res 1 --iters 20 $cfg >> $out/primal_shapes.txt 2>&1 || { tail -5 $out/primal_shapes.txt; exit 1; }
+for lib in "" "--lib cmf_amd/csrc/_obj/dbg_WSKIP.so" "--lib cmf_amd/csrc/_obj/dbg_NORING.so"; do
+  for cfg in "--B 256 --hw 28" "--B 256 --hw 28 --res 0" "--B 512 --hw 14"; do
+    timeout -k 10 120 python tools/bench_conv.py $lib $cfg --fmode bits >> $out/variants.txt 2>&1 || { tail -5 $out/variants.txt; exit 1; }
+  done
 done
-grep -v amdgpu.ids $out/primal_shapes.txt
+grep -v amdgpu.ids $out/variants.txt
 timeout -k 10 900 python -m pytest tests/test_gpu_round3.py -x -q -m gpu -s > $out/tests_round3.log 2>&1; rc=$?
 tail -15 $out/tests_round3.log
 [ $rc -ne 0 ] && exit $rc
