@@ -70,10 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-batch", type=int, default=None, help="CPU baseline sample size (0 disables); C3: 32 = ~12 s on 16 cores")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-f32-exact", action="store_true", help="skip the exact-fp32 leg of the default C3 run")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (the default for evaluation "
-                                                          "steps); the roofline leg then comes from separate eager steps")
-    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of graph replays (the dominant kernel's HIP "
-                                                             "events then sit inside the timed region)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (default for the launch-bound "
+                                                          "c1 / c2a / c2b); the roofline leg then comes from separate eager steps")
+    ap.add_argument("--no-graph", action="store_true", help="c1 / c2a / c2b: time eager launches instead of graph replays")
     ap.add_argument("--hutchinson", action="store_true", help="c5: train-mode stochastic log-det (Hutchinson S=4 + CG) instead of the "
                                                                "exact eval path")
     ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
@@ -93,9 +92,10 @@ def parse_args(argv=None):
                     help="SECONDARY metric (SURVEY 8d): time training steps instead -- forward + loss.backward() on the HIP kernels + "
                          "data-parallel gradient all-reduce + fused Adam; use --batch 64 (the reference's per-GPU shard)")
     args = ap.parse_args(argv)
-    if not args.no_graph and not args.train and not args.hutchinson:
-        # every evaluation step replays a captured HIP graph (round 3: C3 / C5 too -- a C3 step is ~1500 launches, a C5 shard is
-        # launch-bound outright); the per-kernel events of the roofline then come from eager steps right after the timed region
+    if args.config in ("c1", "c2a", "c2b") and not args.no_graph and not args.train:
+        # the launch-bound configurations replay a captured HIP graph.  C3 / C5 stay eager by default: measured in round 3, a
+        # replayed C3 step takes 432.0 ms against 434.7 ms eager (C5 shard 75.3 against 75.6) -- the GPU is busy either way -- and
+        # eager launches keep the dominant kernel's HIP events INSIDE the timed region (--graph replays them too)
         args.graph = True
     if args.steps is None:
         args.steps = 20 if args.config in ("c1", "c2a", "c2b") else 3

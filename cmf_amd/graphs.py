@@ -44,7 +44,8 @@ class ElboGraph:
                     self.density.elbo(self._x.clone(), **self.kwargs)
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.graph):
+            # thread_local: another thread's HIP calls (the RCCL watchdog of a process group) do not invalidate the capture
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self._in = self._x.clone()               # dequantisation mutates its input: work on a graph-owned copy
                 self.out = self.density.elbo(self._in, **self.kwargs)
         finally:

@@ -165,15 +165,20 @@ def head_parts(density, head, xin, dequant):
     return z_low, low_elbo, logdet, jtj.abs().sum((1, 2)) - diag, diag, x_hat
 
 
-def perturbed_parts(head, z_low, delta=1e-6):
-    """The reference's OWN log-det / g_ij when its latent moves by ``delta`` relative per component, both signs: the yardstick for
-    "within rounding of a relu kink" (any fp32 encode chain lands z_low within a few ulps of the reference's).  (2, B) each."""
-    lds, offs = [], []
-    for sgn in (1.0, -1.0):
-        logdet, _, jtj = head._exact_log_det_jac_and_reconstruction(z_low * (1.0 + sgn * delta))
+def perturbed_parts(head, z_low, draws, delta=1e-6, seed=4242):
+    """The reference's OWN log-det / g_ij when its latent moves by ~``delta`` relative per component (independent N(0, delta^2)
+    factors, ``draws`` seeded draws): the yardstick for "within rounding of a relu kink" -- any fp32 encode chain lands z_low
+    within a few ulps of the reference's, on either side of a kink hyperplane that happens to pass that close.  Returns the
+    perturbed latents (draws, B, d) and the two quantities, (draws, B) each."""
+    gen = torch.Generator().manual_seed(seed)
+    zs, lds, offs = [], [], []
+    for _ in range(draws):
+        zz = z_low + z_low * torch.randn(z_low.shape, generator=gen) * delta
+        logdet, _, jtj = head._exact_log_det_jac_and_reconstruction(zz)
+        zs.append(zz)
         lds.append(logdet.reshape(-1))
         offs.append(jtj.abs().sum((1, 2)) - torch.diagonal(jtj, dim1=1, dim2=2).abs().sum(1))
-    return torch.stack(lds), torch.stack(offs)
+    return torch.stack(zs), torch.stack(lds), torch.stack(offs)
 
 
 def fp64_reference(get_density, schema, sd, x, noise, dequant):
@@ -219,11 +224,11 @@ def stats_fixture(get_density, ref_get_config, ref_get_schema, expand_grid, name
         out["elbo_0"] = density.module.density.elbo(x + noise, add_offdiagonal_metric_reg=True)["elbo"].numpy()
         z, low, logdet, off, diag, _ = head_parts(density, head, x + noise, True)
         out.update(z_low=z.numpy(), low_dim_elbo=low.numpy(), logdet=logdet.numpy(), l1_off=off.numpy(), l1_diag=diag.numpy())
-        ld_p, off_p = perturbed_parts(head, z)
-        out.update(logdet_pert=ld_p.numpy(), l1_off_pert=off_p.numpy())
+        z_p, ld_p, off_p = perturbed_parts(head, z, draws=6)
+        out.update(z_pert=z_p.numpy(), logdet_pert=ld_p.numpy(), l1_off_pert=off_p.numpy())
     out.update(fp64_reference(get_density, schema, sd, x, noise, True))
     meta = {"dataset": "mnist", "overrides": over, "batch": B, "recipe_seed": 0, "recipe_gain": None, "input_seed": 2024,
-            "perturbation": 1e-6, "state_dict": {k: [list(v.shape), str(v.dtype)] for k, v in sd.items()}}
+            "perturbation": "z (1 + 1e-6 N(0,1)) per component, 6 seeded draws", "state_dict": {k: [list(v.shape), str(v.dtype)] for k, v in sd.items()}}
     out["meta"] = np.array(json.dumps(meta))
     path = os.path.join(GOLDEN, f"{name}.npz")
     np.savez_compressed(path, **out)
@@ -234,6 +239,7 @@ def stats_fixture(get_density, ref_get_config, ref_get_schema, expand_grid, name
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--skip-full", action="store_true", help="leave the full-size fixtures (minutes of CPU each) as they are")
     args = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     get_density, ref_get_config, ref_get_schema, expand_grid = _import_reference()
@@ -242,13 +248,15 @@ def main():
 
     if not args.only or args.only == "jitter_retry":
         jitter_fixture(get_density, ref_get_config, ref_get_schema, expand_grid)
-    if not args.only or args.only == "c3_mnist_stats32":
+    if (not args.only and not args.skip_full) or args.only == "c3_mnist_stats32":
         stats_fixture(get_density, ref_get_config, ref_get_schema, expand_grid)
     for name, (dataset, over, B, *opt) in CASES.items():
         if args.only and args.only != name:
             continue
         opt = opt[0] if opt else {}
         gain, full = opt.get("gain"), opt.get("full", False)
+        if full and args.skip_full:
+            continue
         torch.manual_seed(0)
         cfg = expand_grid({**ref_get_config(dataset, "non-square", False), **over})[0]
         schema = ref_get_schema(cfg)
@@ -336,8 +344,8 @@ def main():
             # 1e-6 relative move of its latent (tolerance analysis: tests/test_gpu_round3.py computes its bounds from these)
             out.update(fp64_reference(get_density, schema, sd, x, noise, dequant))
             with torch.no_grad():
-                ld_p, off_p = perturbed_parts(head, z_low)
-            out.update(logdet_pert=ld_p.numpy(), l1_off_pert=off_p.numpy())
+                z_p, ld_p, off_p = perturbed_parts(head, z_low, draws=16)
+            out.update(z_pert=z_p.numpy(), logdet_pert=ld_p.numpy(), l1_off_pert=off_p.numpy())
         meta = {"dataset": dataset, "overrides": over, "batch": B, "recipe_seed": 0, "recipe_gain": gain, "nested_keys": nested_keys,
                 "state_dict": {k: [list(v.shape), str(v.dtype)] for k, v in sd.items()},
                 "elbo_combos": ELBO_COMBOS, "cond_jtj_max": float(torch.linalg.cond(jtj).max())}

@@ -79,15 +79,16 @@ FULL = ["c3_mnist_full", "c3_mnist_full_cond", "c5_cifar_full"]
 
 def kink_tolerance(g, base=1e-4):
     """End-to-end tolerance of a fixture, COMPUTED from the reference's own data: ``base`` unless the float32 reference itself
-    moves by more when its latent moves by 1e-6 relative (``logdet_pert`` / ``l1_off_pert``, written by oracle/make_golden.py:
-    both signs) -- i.e. unless the fixture point sits within rounding of a relu kink, where any fp32 encode chain may land on the
-    other side.  Then: 3 x that movement (relative, worst sample)."""
+    moves by more when its latent moves by ~1e-6 relative per component (``logdet_pert`` / ``l1_off_pert``, written by
+    oracle/make_golden.py: seeded random draws) -- i.e. unless the fixture point sits within rounding of a relu kink, where any fp32 encode chain may land on the
+    other side.  Then: 3 x that movement (max-norm over the batch, like the assertions it feeds)."""
     if "logdet_pert" not in g:
         return base
     ld = g["logdet"].double().reshape(-1)
     off = (g["jtj"].abs().sum((1, 2)) - torch.diagonal(g["jtj"], dim1=1, dim2=2).abs().sum(1)).double()
-    move = max(float(((g["logdet_pert"].double() - ld).abs() / ld.abs().clamp_min(1e-12)).max()),
-               float(((g["l1_off_pert"].double() - off).abs() / off.abs().clamp_min(1e-12)).max()))
+    # in the max-norm the end-to-end assertions of test_parts_match_reference_vectors use (test_gpu_parity.rel)
+    move = max(float((g["logdet_pert"].double() - ld).abs().max() / ld.abs().max()),
+               float((g["l1_off_pert"].double() - off).abs().max() / off.abs().max()))
     return max(base, 3.0 * move)
 
 
@@ -102,7 +103,7 @@ def fp64_bound(fp64, ref32, pert=None, extra=None, rel=1e-4, k=3.0, abs_floor=No
     fp64, ref32 = fp64.double().reshape(-1), ref32.double().reshape(-1)
     yard = (ref32 - fp64).abs()
     if pert is not None:
-        yard = torch.maximum(yard, (pert.double().reshape(2, -1) - ref32).abs().max(0).values)
+        yard = torch.maximum(yard, (pert.double().reshape(-1, ref32.numel()) - ref32).abs().max(0).values)
     if extra is not None:
         yard = yard + extra.double().reshape(-1)
     floor = 0.01 * fp64.abs().max()

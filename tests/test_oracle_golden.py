@@ -97,8 +97,8 @@ def test_fp64_oracle_vs_fp64_reference(name):
 @pytest.mark.parametrize("name", ["c1_sphere", "c2b_hepmass_cond1e3", "mini_mnist", "mini_cifar_cond1e2"])
 def test_fp64_oracle_parts_vs_fp64_reference(name):
     """Round 3: the float64 reference's log det J^T J, g_ij / g_kk sums and low-dimensional elbo (``*_fp64`` keys) against the
-    float64 oracle, and the float32 reference's own movement under the +-1e-6 latent perturbation (``*_pert``) against the
-    float32 oracle at the same perturbed latents -- the yardsticks tests/test_gpu_round3.py builds its per-sample bounds from."""
+    float64 oracle, and the float32 reference's own movement under the seeded ~1e-6 relative latent perturbations (``*_pert``)
+    against the float32 oracle at the same perturbed latents (``z_pert``) -- the yardsticks tests/test_gpu_round3.py builds its per-sample bounds from."""
     g, meta = load_golden(name)
     cfg, schema, x_shape, ops, sd64 = golden_model(meta, dtype=torch.float64)
     noise = g.get("noise")
@@ -113,8 +113,8 @@ def test_fp64_oracle_parts_vs_fp64_reference(name):
     _, _, _, ops32, sd32 = golden_model(meta)
     pre, hd, flow_ops, base, prior_ops = O.split_ops(ops32)
     with torch.no_grad():
-        for i, sgn in enumerate((1.0, -1.0)):
-            jtj, _, _ = O.jtj_batched(sd32, flow_ops, base, g["z_low"] * (1.0 + sgn * 1e-6))
+        for i in range(0, g["z_pert"].shape[0], 5):                      # every fifth draw: seconds
+            jtj, _, _ = O.jtj_batched(sd32, flow_ops, base, g["z_pert"][i])
             logdet, _, _ = O.cholesky_logdet(jtj)
             off = jtj.abs().sum((1, 2)) - torch.diagonal(jtj, dim1=1, dim2=2).abs().sum(1)
             assert rel(logdet.reshape(-1), g["logdet_pert"][i]) < 1e-4 and rel(off, g["l1_off_pert"][i]) < 1e-4
