@@ -568,8 +568,11 @@ class _DerivedCache:
         if hit is not None and hit[0]() is sources[0]:
             old, new = hit[2], out
             olds, news = (old, new) if isinstance(old, tuple) else ((old,), (new,))
-            if len(olds) == len(news) and all(o.shape == n.shape and o.device == n.device for o, n in zip(olds, news)):
-                for o, n in zip(olds, news):
+            tensors = [(o, n) for o, n in zip(olds, news) if torch.is_tensor(o) or torch.is_tensor(n)]
+            if len(olds) == len(news) and all(torch.is_tensor(o) and torch.is_tensor(n) and o.shape == n.shape and o.dtype == n.dtype
+                                               and o.device == n.device for o, n in tensors) \
+                    and all(o == n for o, n in zip(olds, news) if not (torch.is_tensor(o) or torch.is_tensor(n))):
+                for o, n in tensors:                       # same layout (the non-tensor parts -- offsets, widths -- are unchanged)
                     o.copy_(n)
                 out = old
         if len(self._store) > 4096:
