@@ -337,9 +337,9 @@ def roofline_of(name, n, ms, flops, nbytes, step_ms_total, precision, B, pmc=Tru
                           "fp32 accumulate)",
                 "fp32_equivalent_tflops": tf, "bf16_products_per_fp32_product": 3,
                 # context, not the contract's peak: what a loop of nothing but this MFMA sustains on live random operands on every
-                # SIMD (tools/ubench/mfmapower.py, profiles/r02_mfma_sustained.txt: the chip lowers its clock under the load)
+                # SIMD (tools/ubench/mfmapower.py, profiles/r03_mfma_sustained.txt: the chip lowers its clock under the load)
                 "live_data_mfma_ceiling": {"frac_of_peak": 0.72, "frac_of_ceiling": 3.0 * tf / BF16_MFMA_PEAK_TFLOPS / 0.72,
-                                           "source": "profiles/r02_mfma_sustained.txt (measured once, not by this run)"},
+                                           "source": "profiles/r03_mfma_sustained.txt (tools/ubench/mfmapower.py; measured once per round, not by this run)"},
                 "hbm_view": {"algorithmic_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}, **common}
     if name.startswith("conv_tangent") or name.startswith("mlp_") or name == "gram_cholesky":
         traffic, note = pmc_traffic("f32", B) if (name == "conv_tangent_t9_ci64_co64" and pmc) else (None, None)

@@ -22,6 +22,14 @@ cp(os.path.join(src, "eval", "pmc_conv_tangent_bf16x3.json"), "pmc_conv_tangent_
 cp(os.path.join(src, "train", "kernel_stats.csv"), f"{pre}_train_kernel_stats.csv")
 cp(os.path.join(src, "wgrad", "pmc_conv_wgrad.json"), f"{pre}_pmc_conv_wgrad.json")
 cp(os.path.join(src, "train_step_b64.txt"), f"{pre}_train_step_b64.txt")
+cp(os.path.join(src, "c5train", "kernel_stats.csv"), f"{pre}_c5_train_kernel_stats.csv")
+if os.path.exists(os.path.join(src, "c5_train_variants.txt")):
+    lines = [l for l in open(os.path.join(src, "c5_train_variants.txt")) if l.startswith("C5 train")]
+    open(os.path.join(dst, f"{pre}_c5_train_variants.txt"), "w").write(
+        "# python tools/exp_c5_train.py --modes 16,32,full ; --modes 32 --B 256   (one MI355X: CIFAR d=128, train-mode Hutchinson S=4 + CG, fwd + loss.backward() + Adam;\n"
+        "# mode = column slots of the low-rank sweep (HUTCH_LOWRANK_NC) or the d-column backward of rounds 1-2)\n" + "".join(lines))
+    copied.append(f"{pre}_c5_train_variants.txt")
+cp(os.path.join(src, "mfma_sustained.txt"), f"{pre}_mfma_sustained.txt")
 if os.path.exists(os.path.join(src, "gpu_tests.log")):
     open(os.path.join(dst, f"{pre}_gpu_tests_summary.txt"), "w").write("".join(open(os.path.join(src, "gpu_tests.log")).readlines()[-3:]))
     copied.append(f"{pre}_gpu_tests_summary.txt")
