@@ -8,8 +8,8 @@ tag=${1:-prof}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-B2="python3 bench.py --steps 2 --warmup 1 --cpu-batch 0 --no-kernel-timer --no-f32-exact"
-B1="python3 bench.py --steps 1 --warmup 0 --cpu-batch 0 --no-kernel-timer --no-f32-exact"
+B2="python3 bench.py --steps 2 --warmup 1 --cpu-batch 0 --no-kernel-timer --no-f32-exact --no-legs"
+B1="python3 bench.py --steps 1 --warmup 0 --cpu-batch 0 --no-kernel-timer --no-f32-exact --no-legs"
 timeout -k 10 150 rocprofv3 --kernel-trace --stats -d $out/stats -- $B2 > $out/stats.log 2>&1 || { tail -5 $out/stats.log; exit 1; }
 timeout -k 10 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/pmc_sq -- $B1 > $out/pmc_sq.log 2>&1 || { tail -5 $out/pmc_sq.log; exit 1; }
 timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pmc_fetch -- $B1 > $out/pmc_fetch.log 2>&1 || { tail -5 $out/pmc_fetch.log; exit 1; }

@@ -5,7 +5,7 @@
 """
 import glob, sqlite3, sys, os
 d, out = sys.argv[1], sys.argv[2]
-cmd = sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-batch 0 --no-kernel-timer --no-f32-exact  (MI355X, C3 B=512; 3 steps in the trace; durations in us)"
+cmd = sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --cpu-batch 0 --no-kernel-timer --no-f32-exact --no-legs  (MI355X, C3 B=512; 3 steps in the trace; durations in us)"
 rows = []
 for path in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
     db = sqlite3.connect(path)
