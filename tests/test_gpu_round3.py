@@ -74,6 +74,12 @@ def test_lowrank_hutchinson_gradients_match_oracle_autograd(nc_quantum, hidden, 
     print(f"low-rank nc={nc_quantum} diag={diag}: {len(errs)} tensors, worst {errs[worst]:.1e} ({worst}), dz {rel(out['dz_low'], want[-1]):.1e}")
     assert len(errs) >= 40 and errs[worst] < 2e-3, (worst, errs[worst])
     assert rel(out["dz_low"], want[-1]) < 2e-3
+    # recomputation per coupling layer (keep=False: only each layer's inputs are kept for the n-column sweep): same gradients
+    st3 = head.head_terms_forward(z_low.cuda(), tangents=True, hutch_eps=eps.cuda(), add_diag=diag, keep=False)
+    assert st3["hutch"]["lowrank"] is not None and st3["ctx"][0][0] == "recompute"
+    out3 = head.head_terms_backward(z_low.cuda(), None, g_logdet=a.cuda(), g_l1diag=c.cuda() if diag else None, state=st3)
+    for k in errs:
+        assert rel(out3["grads"][named[k]], out["grads"][named[k]]) < 1e-5, k
     # the d-column backward (hutch_lowrank = False) gives the same gradients from the same probes
     head.hutch_lowrank = False
     st2 = head.head_terms_forward(z_low.cuda(), tangents=True, hutch_eps=eps.cuda(), add_diag=diag)
