@@ -418,7 +418,7 @@ def capture_graph(wl):
 HIDDEN_CONV = "conv_tangent_t9_ci64_co64"        # KernelTimer name of the dominant kernel family of the image configurations
 
 
-def eval_leg(name, config, B, rank, world, device, steps, warmup, precision, scaling, graph=False, hutchinson=False):
+def eval_leg(config, B, rank, world, device, steps, warmup, precision, scaling, graph=False, hutchinson=False):
     """A secondary evaluation measurement inside the same process (group): returns the sub-object for rank 0's line."""
     import torch
     wl = Workload(config, B, rank, device)
@@ -520,9 +520,9 @@ def run_rank(args):
     legs = {}
     if default_run and world > 1:
         # BASELINE configs[3]: the SAME global batch of 512 sharded over the ranks; configs[4]: CIFAR d=128, 32 samples per GPU
-        legs["strong_c3"] = eval_leg("strong_c3", "c3", max(1, 512 // world), rank, world, device, args.leg_steps, 1, args.precision, "strong",
+        legs["strong_c3"] = eval_leg("c3", max(1, 512 // world), rank, world, device, args.leg_steps, 1, args.precision, "strong",
                                      graph=args.graph)
-        legs["c5"] = eval_leg("c5", "c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph)
+        legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph)
     f32 = None
     if default_run and world == 1:
         if not args.no_f32_exact:
@@ -536,8 +536,8 @@ def run_rank(args):
                 tf = fl / (ms * 1e-3) / 1e12
                 f32.update(kernel="conv_tangent_kernel<9,4,7> (fp32 MFMA)", kernel_avg_ms=ms / n, kernel_tflops=tf,
                            peak=FP32_MFMA_PEAK_TFLOPS, frac=tf / FP32_MFMA_PEAK_TFLOPS)
-        legs["c5"] = eval_leg("c5", "c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph)
-        legs["c2b"] = eval_leg("c2b", "c2b", 4096, rank, world, device, 20, 2, args.precision, "weak", graph=True)
+        legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph)
+        legs["c2b"] = eval_leg("c2b", 4096, rank, world, device, 20, 2, args.precision, "weak", graph=True)
         wl5 = Workload("c5", 32, rank, device)
         legs["c5_train"] = train_leg(args.leg_steps, 1, "c5", wl5.inner, wl5.x, 32, rank, world, device, wl5.off)
         del wl5

@@ -1070,7 +1070,8 @@ class NonSquareHeadDensity(Density):
     def train_backward(self, state, d_elbo, grads=None):
         """Backward half: ``d_elbo`` (B,) or (B, 1) = d loss / d elbo_b (``-1/B`` for ``loss = -elbo.mean()``).  Accumulates
         d loss / d theta of every parameter below this head into ``grads`` (dict parameter -> tensor) and returns it."""
-        grads = {} if grads is None else grads
+        if grads is None:                                  # one zero-filled pool instead of a fill launch per parameter tensor
+            grads = E.GradPool([p for p in self.parameters() if p.requires_grad], d_elbo.device)
         prog = self.program
         w = d_elbo.detach().reshape(-1).to(torch.float32)
         lam = float(self.regularization_param)

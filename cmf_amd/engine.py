@@ -566,15 +566,17 @@ class _DerivedCache:
             return hit[2]
         out = build()
         if hit is not None and hit[0]() is sources[0]:
-            old, new = hit[2], out
-            olds, news = (old, new) if isinstance(old, tuple) else ((old,), (new,))
-            tensors = [(o, n) for o, n in zip(olds, news) if torch.is_tensor(o) or torch.is_tensor(n)]
-            if len(olds) == len(news) and all(torch.is_tensor(o) and torch.is_tensor(n) and o.shape == n.shape and o.dtype == n.dtype
-                                               and o.device == n.device for o, n in tensors) \
-                    and all(o == n for o, n in zip(olds, news) if not (torch.is_tensor(o) or torch.is_tensor(n))):
-                for o, n in tensors:                       # same layout (the non-tensor parts -- offsets, widths -- are unchanged)
-                    o.copy_(n)
-                out = old
+            # same layout as the stale entry (equal shapes / dtypes; equal non-tensor parts such as offsets and widths): refresh
+            # the OLD tensors in place, so whatever is keyed on their identity (the pack cache) follows instead of piling up
+            olds, news = (hit[2], out) if isinstance(out, tuple) else ((hit[2],), (out,))
+            same = len(olds) == len(news) and all(
+                (o.shape == n.shape and o.dtype == n.dtype and o.device == n.device) if torch.is_tensor(o) and torch.is_tensor(n)
+                else (not torch.is_tensor(o) and not torch.is_tensor(n) and o == n) for o, n in zip(olds, news))
+            if same:
+                for o, n in zip(olds, news):
+                    if torch.is_tensor(o):
+                        o.copy_(n)
+                out = hit[2]
         if len(self._store) > 4096:
             self._store = {k: v for k, v in self._store.items() if v[0]() is not None}
         self._store[key] = (weakref.ref(sources[0]), ver, out)
@@ -1035,10 +1037,32 @@ def net_tangent(net, T, view, acts, transpose_packs=False, save=None):
     return out
 
 
+class GradPool(dict):
+    """``grads`` dictionary (parameter -> gradient tensor) whose tensors are slices of ONE zero-filled buffer: a training step
+    touches ~470 parameter tensors, and a ``zeros_like`` each was ~470 fill launches of 4 us per backward pass.  Only the parameters a
+    backward pass actually reaches get an entry, exactly like the plain dict (parameters outside the graph keep ``grad = None``, as in
+    the reference's autograd)."""
+
+    def __init__(self, params, device):
+        super().__init__()
+        n = sum((p.numel() + 3) // 4 * 4 for p in params)             # 16-byte aligned slices
+        self._pool = torch.zeros(max(n, 4), dtype=torch.float32, device=device)
+        self._used = 0
+
+    def zeros_for(self, weight):
+        n = weight.numel()
+        if self._used + n > self._pool.numel():                       # a parameter the pool was not sized for
+            return torch.zeros_like(weight, dtype=torch.float32).contiguous()
+        g = self._pool[self._used:self._used + n].view(weight.shape)
+        self._used += (n + 3) // 4 * 4
+        return g
+
+
 def _grad_of(grads, weight):
     g = grads.get(weight)
     if g is None:
-        g = grads[weight] = torch.zeros_like(weight, dtype=torch.float32).contiguous()
+        g = grads[weight] = (grads.zeros_for(weight) if isinstance(grads, GradPool)
+                             else torch.zeros_like(weight, dtype=torch.float32).contiguous())
     return g
 
 
