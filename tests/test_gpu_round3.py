@@ -275,3 +275,27 @@ def test_two_threads_two_streams_one_device():
     for i in range(2):
         assert torch.equal(got[i][0], want[i][0]), i
         assert abs(float(got[i][1] - want[i][1])) <= 1e-9 * abs(float(want[i][1])), i
+
+
+def test_nested_prior_dict_under_autograd():
+    """``head.nested_prior_dict = True`` must hold in train mode too -- the autograd path used to hand back the flat
+    ``{"elbo", "low-dim-x"}`` whatever the flag said.  Same keys at every level as the reference's chain (fixture ``nested_keys``),
+    same elbo values as the no-grad path, and the elbo still carries the autograd node."""
+    g, meta, cfg, dens = build("mini_mnist")
+    head = find_head(dens)
+    head.nested_prior_dict = True
+    y = g["head_input"].cuda()
+    with torch.no_grad():
+        want = head.elbo(y.clone(), add_offdiagonal_metric_reg=True)
+    dens.train()
+    with torch.enable_grad():
+        got = head.elbo(y.clone(), add_offdiagonal_metric_reg=True)
+    assert got["elbo"].requires_grad and rel(got["elbo"], want["elbo"]) < 1e-6
+    a, b, level = got["prior-dict"], want["prior-dict"], 0
+    while isinstance(a, dict):
+        assert sorted(a.keys()) == sorted(b.keys()) == meta["nested_keys"][level], level
+        assert rel(a["elbo"], b["elbo"]) < 1e-6
+        a, b, level = a.get("prior-dict"), b.get("prior-dict"), level + 1
+    assert level == len(meta["nested_keys"]) and not isinstance(b, dict)
+    (-got["elbo"].mean()).backward()
+    assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in dens.parameters())
