@@ -55,6 +55,7 @@ class MlpCouplerArgs(C.Structure):
 SIGNATURES = {
     "cmf_version": (C.c_char_p, []),
     "cmf_pack_weight": (_i, [_fp, _fp, _i, _i, _i, _i, C.POINTER(_ll), _fp]),
+    "cmf_pack_weights_batched": (_i, [_fp, _i, _fp]),
     "cmf_conv_tangent": (_i, [C.POINTER(ConvTangentArgs), _fp]),
     "cmf_pack_weight_bf16x3": (_i, [_fp, _fp, _i, _i, C.POINTER(_ll), _fp]),
     "cmf_pack_weight_bf16x3_t": (_i, [_fp, _fp, _i, _i, _i, C.POINTER(_ll), _fp]),

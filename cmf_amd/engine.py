@@ -156,6 +156,7 @@ class _PackCache:
     def __init__(self):
         self._store = {}
         self.generation = 0
+        self._tables = {}                                          # device -> (signature, descriptor table) of the batched refresh
 
     def invalidate(self):
         """Every cached pack is stale from now on.  Called by writers that change parameter VALUES without touching the
@@ -170,6 +171,13 @@ class _PackCache:
         hit = self._store.get(key)
         if hit is not None and hit[0]() is weight and hit[1] == ver:
             return hit[2]
+        if hit is not None and hit[0]() is weight and hit[1][:4] == ver[:4] and self.BATCHED_REFRESH:
+            # only the generation moved: an optimiser step rewrote the parameter VALUES (FlatOptimizer.step -> invalidate()).
+            # Every pack of the model is stale in the same way: rebuild them all in ONE launch instead of one launch each
+            self._refresh_generation(weight.device)
+            hit = self._store.get(key)
+            if hit[1] == ver:
+                return hit[2]
         lib = _lib.load()
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
         n = C.c_longlong(0)
@@ -190,8 +198,44 @@ class _PackCache:
             _lib.check(lib.cmf_pack_weight(_p(w), _p(out), cout, cin, taps, int(transpose), None, _stream()), "cmf_pack_weight")
         if len(self._store) > 4096:                                   # drop entries whose parameter is gone
             self._store = {k: v for k, v in self._store.items() if v[0]() is not None}
-        self._store[key] = (weakref.ref(weight), ver, out)
+        self._store[key] = (weakref.ref(weight), ver, out, int(taps))
         return out
+
+    #: False: every stale pack is rebuilt by its own launch on first use (rounds 1 - 2)
+    BATCHED_REFRESH = True
+
+    def _refresh_generation(self, device):
+        """Re-pack, in one ``cmf_pack_weights_batched`` launch, every entry on ``device`` whose parameter is alive and unchanged
+        but for the generation counter (its values were rewritten under it by the fused optimiser step)."""
+        todo = []
+        for key, (ref, ver, out, taps) in self._store.items():
+            w = ref()
+            if (w is None or ver[4] == self.generation or w.device != device or not w.is_contiguous()
+                    or (w._version, w.data_ptr(), w.device, tuple(w.shape)) != ver[:4]):
+                continue
+            todo.append((key, w, ver, out, taps))
+        if not todo:
+            return
+        desc = np.dtype([("w", "<u8"), ("out", "<u8"), ("total", "<i8"), ("cout", "<i4"), ("cin", "<i4"), ("taps", "<i4"),
+                         ("transpose", "<i4"), ("kind", "<i4"), ("reserved", "<i4")])            # = cmf_pack_desc (include/cmf_amd.h)
+        sig = tuple((key, w.data_ptr(), out.data_ptr()) for key, w, ver, out, taps in todo)
+        cached = self._tables.get(device)
+        if cached is not None and cached[0] == sig:
+            table = cached[1]
+        else:
+            arr = np.zeros(len(todo), dtype=desc)
+            for i, (key, w, ver, out, taps) in enumerate(todo):
+                _, transpose, bf16x3 = key
+                cout, cin = int(w.shape[0]), int(w.shape[1])
+                if bf16x3 and transpose:
+                    cout, cin = cin, cout
+                arr[i] = (w.data_ptr(), out.data_ptr(), out.numel() * out.element_size() // (2 if bf16x3 else 4), cout, cin, taps,
+                          int(transpose), int(bf16x3), 0)
+            table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+            self._tables[device] = (sig, table)
+        _lib.check(_lib.load().cmf_pack_weights_batched(_p(table), len(todo), _stream()), "cmf_pack_weights_batched")
+        for key, w, ver, out, taps in todo:
+            self._store[key] = (self._store[key][0], ver[:4] + (self.generation,), out, taps)
 
 
 PACKS = _PackCache()

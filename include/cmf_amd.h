@@ -59,6 +59,16 @@ const char* cmf_version(void);
 int cmf_pack_weight(const float* w, float* out, int cout, int cin, int taps, int transpose,
                     long long* out_floats, void* stream);
 
+/* Every stale pack of a model in ONE launch (a training step re-packs ~780 weights: round 3).  `table` is a DEVICE array of n
+ * descriptors; entry k writes `total` elements of layout `kind` (0: cmf_pack_weight's floats, 1: cmf_pack_weight_bf16x3_t's bf16
+ * halves) of the weight `w` to `out`, exactly as the single-weight entry points do.  For kind 1 with transpose != 0, cout / cin are
+ * the ADJOINT operator's (already swapped), as cmf_pack_weight_bf16x3_t expects them. */
+typedef struct {
+  const float* w; void* out; long long total;
+  int cout, cin, taps, transpose, kind, reserved;
+} cmf_pack_desc;
+int cmf_pack_weights_batched(const cmf_pack_desc* table, int n, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Tangent convolution / linear layer on fp32 MFMA (v_mfma_f32_16x16x4_f32).
  * Replaces, for all d Jacobian columns at once, the tangent half of get_conv2d_jvp / get_linear_jvp

@@ -299,3 +299,58 @@ def test_nested_prior_dict_under_autograd():
     assert level == len(meta["nested_keys"]) and not isinstance(b, dict)
     (-got["elbo"].mean()).backward()
     assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in dens.parameters())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# batched weight re-packing after an optimiser step
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def test_batched_repack_equals_the_single_weight_packs():
+    """``cmf_pack_weights_batched`` (one launch for every stale pack after ``FlatOptimizer.step``) writes bit for bit what
+    ``cmf_pack_weight`` / ``cmf_pack_weight_bf16x3_t`` write one weight at a time: fp32 and split-precision layouts, forward and
+    adjoint, 3x3 and 1x1, padded channel counts.  The parameters' VALUES change under the cache without any version counter
+    moving (the round-1 failure mode): the refresh is triggered by ``invalidate()`` alone."""
+    import ctypes as C
+    from cmf_amd import engine as E, _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(1)
+    shapes = [(64, 64, 3, 3), (64, 2, 3, 3), (4, 64, 1, 1), (128, 64, 3, 3), (32, 17)]
+    flat = torch.randn(sum(int(np.prod(s)) for s in shapes), generator=gen).cuda()
+    params, off = [], 0
+    for s in shapes:
+        p = torch.nn.Parameter(torch.empty(0))
+        p.data = flat[off:off + int(np.prod(s))].view(s)              # views of one flat buffer, like FlatOptimizer's parameters
+        params.append(p)
+        off += int(np.prod(s))
+    cache = E._PackCache()
+    forms = []
+    for p in params:
+        taps = 9 if p.dim() == 4 and p.shape[-1] == 3 else 1
+        for transpose in (False, True):
+            forms.append((p, taps, transpose, False))
+            cin = p.shape[0] if transpose else p.shape[1]
+            cout = p.shape[1] if transpose else p.shape[0]
+            if taps == 9 and cin % 32 == 0 and (cout % 64 == 0 or cout == 32):
+                forms.append((p, taps, transpose, True))
+    first = [cache.get(p, taps, tr, bf).clone() for p, taps, tr, bf in forms]
+    versions = [p._version for p in params]
+    flat.mul_(1.5).add_(0.25)                                              # new values, no parameter version moves
+    assert [p._version for p in params] == versions
+    assert all(torch.equal(cache.get(p, taps, tr, bf), a) for (p, taps, tr, bf), a in zip(forms, first)), "stale hit expected"
+    cache.invalidate()
+    got = cache.get(*forms[0])                                             # one get() refreshes every entry
+    assert all(v[1][4] == cache.generation for v in cache._store.values())
+    for (p, taps, tr, bf), old in zip(forms, first):
+        new = cache.get(p, taps, tr, bf)
+        cout, cin = int(p.shape[0]), int(p.shape[1])
+        ref = torch.empty_like(new)
+        if bf:
+            if tr:
+                cout, cin = cin, cout
+            _lib.check(lib.cmf_pack_weight_bf16x3_t(E._p(p.detach().contiguous()), E._p(ref), cout, cin, int(tr), None, E._stream()), "pack")
+        else:
+            _lib.check(lib.cmf_pack_weight(E._p(p.detach().contiguous()), E._p(ref), cout, cin, taps, int(tr), None, E._stream()), "pack")
+        assert torch.equal(new, ref), (tuple(p.shape), taps, tr, bf)
+        assert not torch.equal(new, old)
+    assert len(forms) >= 14
