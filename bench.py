@@ -154,8 +154,8 @@ def spawn_ranks(args, argv, script=None):
     reader.join(timeout=5)
     codes = [p.returncode for p in procs]
     lines = [l for l in ("".join(o or "" for o in out0)).splitlines() if l.strip()]
-    for l in lines:
-        print(l, flush=True)
+    for l in lines:                                    # the JSON line to stdout; anything a backend chattered (gloo does) to stderr
+        print(l, flush=True, file=sys.stdout if l.lstrip().startswith("{") else sys.stderr)
     if timed_out:
         print(f"[bench] ranks still running after --launch-timeout {args.launch_timeout:.0f} s: stopped (codes {codes})", file=sys.stderr)
         return 124
