@@ -426,7 +426,7 @@ def eval_leg(config, B, rank, world, device, steps, warmup, precision, scaling, 
         wl.density.train()
     g = None
     if graph:
-        g, why = capture_graph(wl)
+        g, _ = capture_graph(wl)
         graph = g is not None
     select = None if graph else ((lambda n: n == HIDDEN_CONV) if config in ("c3", "c5") else (lambda n: True))
     dt, loss, rows, seen = eval_timed(wl, world, steps, warmup, select, g)
@@ -487,7 +487,7 @@ def run_rank(args):
     E.PRIMAL_PRECISION = args.primal_precision
     B = args.batch // world if args.strong else args.batch
     wl = Workload(args.config, B, rank, device)
-    cfg, schema, shape, sd, density, inner, x, kw = wl.cfg, wl.schema, wl.shape, wl.sd, wl.density, wl.inner, wl.x, wl.kw
+    cfg, schema, shape, sd, density, inner, x = wl.cfg, wl.schema, wl.shape, wl.sd, wl.density, wl.inner, wl.x
     dataset, off, label = wl.dataset, wl.off, wl.label
     if args.hutchinson:
         assert args.config == "c5", "--hutchinson is C5's train-mode stochastic log-det"

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import COND, SMALL, fp64_bound, golden_model, load_golden
+from conftest import COND, SMALL, fp64_bound, load_golden
 from test_gpu_parity import build, find_head, inner, rel
 
 pytestmark = pytest.mark.gpu
@@ -311,7 +311,6 @@ def test_batched_repack_equals_the_single_weight_packs():
     ``cmf_pack_weight`` / ``cmf_pack_weight_bf16x3_t`` write one weight at a time: fp32 and split-precision layouts, forward and
     adjoint, 3x3 and 1x1, padded channel counts.  The parameters' VALUES change under the cache without any version counter
     moving (the round-1 failure mode): the refresh is triggered by ``invalidate()`` alone."""
-    import ctypes as C
     from cmf_amd import engine as E, _lib
     lib = _lib.load()
     gen = torch.Generator().manual_seed(1)
