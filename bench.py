@@ -77,9 +77,10 @@ def parse_args(argv=None):
                                                                "exact eval path")
     ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
                     help="arithmetic of the 3x3 tangent convolutions (both are fp32-grade; see DESIGN.md 4.1b)")
-    ap.add_argument("--primal-precision", choices=["f32", "bf16x3"], default="f32",
-                    help="arithmetic of the PRIMAL hidden convs (relu masks come from these activations): f32 = exact fp32 "
-                         "products (default, parity-grade), bf16x3 = split precision, ~9 %% faster (DESIGN.md 4.2)")
+    ap.add_argument("--primal-precision", choices=["f16x3", "f32", "bf16x3"], default="f16x3",
+                    help="arithmetic of the PRIMAL hidden convs (relu masks come from these activations): f16x3 = fp16 split with "
+                         "exact power-of-two scales (default: fp32-grade per product, bf16 MFMA rate), f32 = exact fp32 products, "
+                         "bf16x3 = bf16 split (experiment: ~15x more relu-mask flips; DESIGN.md 4.2)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 "
                                                        "on a one-GPU box together with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (never a measurement)")
@@ -350,13 +351,22 @@ def roofline_of(name, n, ms, flops, nbytes, step_ms_total, precision, B, pmc=Tru
             "kernel": name, **common}
 
 
+def set_kernels(density, tangent=None, primal=None):
+    """Arithmetic of every non-square head below ``density`` (``head.kernels``, engine.KernelConfig); None keeps a field."""
+    from cmf_amd import engine as E
+    for m in density.modules():
+        if isinstance(getattr(m, "kernels", None), E.KernelConfig):
+            m.kernels = E.KernelConfig(tangent or m.kernels.tangent, primal or m.kernels.primal)
+
+
 class Workload:
     """One BASELINE configuration on this rank: model, synthetic shard, elbo kwargs."""
 
-    def __init__(self, config, B, rank, device):
+    def __init__(self, config, B, rank, device, tangent=None, primal=None):
         self.config = config
         self.dataset, over, _, self.off, self.label = CONFIGS[config]
         self.cfg, self.schema, self.shape, self.sd, self.density = make_model(device, dataset=self.dataset, overrides=over)
+        set_kernels(self.density, tangent, primal)
         dequant = self.schema[0]["type"] == "dequantization"
         self.inner = self.density.module.density if dequant else self.density     # noise is part of the synthetic input
         self.B, self.rank, self.device = B, rank, device
@@ -381,19 +391,18 @@ def eval_timed(wl, world, steps, warmup, timer_select=None, graph=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    import contextlib
     with torch.no_grad():
         for _ in range(warmup):
             step()
-        if timer_select is not None:
-            E.TIMER = E.KernelTimer(timer_select)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step()
-        fence()
-        dt = time.perf_counter() - t0
-    rows = E.TIMER.by_name() if E.TIMER is not None else None
-    E.TIMER = None
+        with (E.timing(timer_select) if timer_select is not None else contextlib.nullcontext()) as timer:
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            fence()
+            dt = time.perf_counter() - t0
+    rows = timer.by_name() if timer is not None else None
     tmax = torch.tensor([dt], device=wl.device, dtype=torch.float64)
     seen = 1
     if world > 1:
@@ -418,10 +427,10 @@ def capture_graph(wl):
 HIDDEN_CONV = "conv_tangent_t9_ci64_co64"        # KernelTimer name of the dominant kernel family of the image configurations
 
 
-def eval_leg(config, B, rank, world, device, steps, warmup, precision, scaling, graph=False, hutchinson=False):
+def eval_leg(config, B, rank, world, device, steps, warmup, precision, scaling, graph=False, hutchinson=False, primal=None):
     """A secondary evaluation measurement inside the same process (group): returns the sub-object for rank 0's line."""
     import torch
-    wl = Workload(config, B, rank, device)
+    wl = Workload(config, B, rank, device, precision, primal)
     if hutchinson:
         wl.density.train()
     g = None
@@ -482,11 +491,8 @@ def run_rank(args):
     if world > 1:
         init_group(args, world, device)
 
-    from cmf_amd import engine as E
-    E.TANGENT_PRECISION = args.precision
-    E.PRIMAL_PRECISION = args.primal_precision
     B = args.batch // world if args.strong else args.batch
-    wl = Workload(args.config, B, rank, device)
+    wl = Workload(args.config, B, rank, device, args.precision, args.primal_precision)
     cfg, schema, shape, sd, density, inner, x = wl.cfg, wl.schema, wl.shape, wl.sd, wl.density, wl.inner, wl.x
     dataset, off, label = wl.dataset, wl.off, wl.label
     if args.hutchinson:
@@ -521,24 +527,24 @@ def run_rank(args):
     if default_run and world > 1:
         # BASELINE configs[3]: the SAME global batch of 512 sharded over the ranks; configs[4]: CIFAR d=128, 32 samples per GPU
         legs["strong_c3"] = eval_leg("c3", max(1, 512 // world), rank, world, device, args.leg_steps, 1, args.precision, "strong",
-                                     graph=args.graph)
-        legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph)
+                                     graph=args.graph, primal=args.primal_precision)
+        legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph, primal=args.primal_precision)
     f32 = None
     if default_run and world == 1:
         if not args.no_f32_exact:
             # the same workload with the hidden tangent convs on exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): 3 timed steps
-            E.TANGENT_PRECISION = "f32"
+            set_kernels(wl.density, tangent="f32")
             dt32, _, rows32, _ = eval_timed(wl, 1, 3, 1, None if args.no_kernel_timer else (lambda name: name == HIDDEN_CONV), None)
-            E.TANGENT_PRECISION = args.precision
+            set_kernels(wl.density, tangent=args.precision)
             f32 = {"value": 3 * B / dt32, "unit": "evals/s", "steps": 3, "warmup": 1, "ms_per_step": 1e3 * dt32 / 3, "dtype": "f32"}
             if rows32:
                 name, n, ms, fl, by = dominant(rows32)
                 tf = fl / (ms * 1e-3) / 1e12
                 f32.update(kernel="conv_tangent_kernel<9,4,7> (fp32 MFMA)", kernel_avg_ms=ms / n, kernel_tflops=tf,
                            peak=FP32_MFMA_PEAK_TFLOPS, frac=tf / FP32_MFMA_PEAK_TFLOPS)
-        legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph)
+        legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph, primal=args.primal_precision)
         legs["c2b"] = eval_leg("c2b", 4096, rank, world, device, 20, 2, args.precision, "weak", graph=True)
-        wl5 = Workload("c5", 32, rank, device)
+        wl5 = Workload("c5", 32, rank, device, args.precision, args.primal_precision)
         legs["c5_train"] = train_leg(args.leg_steps, 1, "c5", wl5.inner, wl5.x, 32, rank, world, device, wl5.off)
         del wl5
         torch.cuda.empty_cache()

@@ -27,7 +27,7 @@ class ConvTangentArgs(C.Structure):
                 ("np", _i), ("cin", _i), ("cout", _i), ("H", _i), ("W", _i), ("nc", _i), ("taps", _i),
                 ("bias", _fp), ("f_group", _i), ("x_sl", _ll), ("y_sl", _ll), ("r_sl", _ll),
                 ("fo", _fp), ("fo_np", _ll), ("fo_co", _ll), ("fo_px", _ll), ("fomode", _i),
-                ("mask_out", _fp), ("mask_np", _ll)]
+                ("mask_out", _fp), ("mask_np", _ll), ("amax_in", _fp), ("amax_out", _fp)]
 
 
 class ConvPrimalArgs(C.Structure):
@@ -60,6 +60,9 @@ SIGNATURES = {
     "cmf_pack_weight_bf16x3": (_i, [_fp, _fp, _i, _i, C.POINTER(_ll), _fp]),
     "cmf_pack_weight_bf16x3_t": (_i, [_fp, _fp, _i, _i, _i, C.POINTER(_ll), _fp]),
     "cmf_conv_tangent_bf16x3": (_i, [C.POINTER(ConvTangentArgs), _fp]),
+    "cmf_pack_weight_f16x3": (_i, [_fp, _fp, _i, _i, _i, C.POINTER(_ll), _fp]),
+    "cmf_conv_tangent_f16x3": (_i, [C.POINTER(ConvTangentArgs), _fp]),
+    "cmf_absmax": (_i, [_fp, _ll, _fp, _fp]),
     "cmf_conv_tangent_wgrad_ws": (_ll, [C.POINTER(ConvTangentArgs)]),
     "cmf_conv_tangent_wgrad": (_i, [C.POINTER(ConvTangentArgs), _fp, _fp, _fp, _ll, _fp]),
     "cmf_conv_tangent_wgrad_bf16x3": (_i, [C.POINTER(ConvTangentArgs), _fp, _fp, _fp, _ll, _fp]),

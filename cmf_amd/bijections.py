@@ -141,7 +141,7 @@ class AffineCouplingBijection(Bijection):
                 and E.mlp_coupler_supported(self.net, view, T, 2 * self.cmod)):
             return E.mlp_coupler(self.net, z, T, view, self.maps(z.device), decode=True, lj=lj, ncols=ncols)
         # the split-precision tangent pass reads relu' from bit masks written by the primal pass (engine.BitMask)
-        want = False if T is None else ("bits" if E.TANGENT_PRECISION == "bf16x3" else True)
+        want = False if T is None else ("bits" if E.cfg().tangent == "bf16x3" else True)
         y, g, acts = E.net_primal(self.net, z, view, need_acts=want)
         if T is not None:
             YT = E.net_tangent(self.net, T, view, acts)

@@ -47,6 +47,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -83,6 +84,23 @@ __device__ __forceinline__ unsigned pack_lo(float a, float b) {
   bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
   return __builtin_bit_cast(unsigned, h);
 }
+// fp16 split of a channel pair (F16 variant): hi = RNE fp16 pair, lo = RNE fp16 of the exact remainders.  The remainder is ONE
+// mixed-precision fma per value, e - float(hi) = fma(hi, -1, e) with hi read straight from its half of the packed register
+// (v_fma_mix_f32: op_sel_hi marks source 0 as fp16, op_sel picks the half): 4 VALU per pair against 6 for the bf16 form.
+__device__ __forceinline__ unsigned split_f16(float e, float o, unsigned& lo) {
+  unsigned hb;
+  float re, ro;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hb) : "v"(e), "v"(o));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(re) : "v"(hb), "v"(e));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ro) : "v"(hb), "v"(o));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(re), "v"(ro));
+  return hb;
+}
+// 2^e as a float, e clamped to the normal range
+__device__ __forceinline__ float pow2i(int e) {
+  e = e < -126 ? -126 : e > 127 ? 127 : e;
+  return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
 
 // 16-byte slot of column `col` inside pixel `pix`'s 256-byte row of the X image.  The permutation makes the eight
 // lanes of a ds_write_b128 lane group (4 column quads of two neighbouring pixels, same column-in-quad) cover eight
@@ -102,9 +120,15 @@ __device__ __forceinline__ int xslot(int col, int pix) { return (((col & 3) << 2
 // Two LDS stages (2 x 56 KiB), ONE barrier per 8-channel chunk; both roles execute the same number of barriers.
 // SELF = the input's own elementwise relu is applied on load (primal data in the column slots); a compile-time switch:
 // as a run-time select it made hipcc spill 77 VGPRs in the loader's commit.
-template <int COT, int PXW, int MODE>
+// F16 (cmf_conv_tangent_f16x3, the primal pass): the same kernel on v_mfma_f32_16x16x32_f16 with fp16 hi / lo halves (11 + 11
+// significant bits: ~2^-22 per product instead of 2^-16), exact power-of-two scales around the narrow exponent range (weights
+// packed times 2^k, inputs times the power of two derived from *amax_in; the epilogue multiplies by the inverse, a residual is
+// scaled when it lands), the sign bits of the stored values written as the next conv's relu' bit mask (mask_out) and max(y) raised
+// into *amax_out.  SELF mode only.
+template <int COT, int PXW, int MODE, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
                                                                        int nslices, int ncog, int total) {
+  static_assert(!F16 || (MODE == 2 && COT == 4), "the fp16 variant is the primal pass: SELF mode, 64-channel groups");
   // MODE: 0 = general factor formula, 1 = relu factor (2 instead of 6 VALU per channel in the loader), 2 = SELF (the
   // input's own relu, no factor stream).  Compile-time: every loader VALU instruction delays the MFMA wave it shares
   // a SIMD with.
@@ -125,6 +149,21 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   const bool loader = wave >= 4;
   const int kq = lane >> 4, cl = lane & 15;
   const int nchunks = a.cin / 8;
+  // F16: exact power-of-two scales (wave-uniform).  xscale puts the largest input in [2^13, 2^14); the packed weights carry
+  // 2^k (trailer of cmf_pack_weight_f16x3); accumulators hold 2^k xscale times the result.
+  float xscale = 1.f, oscale = 1.f, rscale = 1.f;
+  if constexpr (F16) {
+    const float amax = a.amax_in ? *a.amax_in : 0.f;
+    const int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);     // amax = m 2^(ex - 126), m in [0.5, 1)
+    int xs = ex == 0 ? 0 : 14 - (ex - 126);
+    xs = xs < -60 ? -60 : xs > 40 ? 40 : xs;
+    const float* trailer = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.w) +
+                                                          (long long)ncog * nchunks * BCfg<COT, PXW>::W_CHUNK_BYTES);
+    const float wscale = trailer[0], winv = trailer[1];
+    xscale = pow2i(xs);
+    oscale = winv * pow2i(-xs);
+    rscale = wscale * xscale;
+  }
 
   // XCD-aware item list.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each): XCD k owns the
   // contiguous logical range [xstart, xstart + xlen), ordered slice-fastest, then tile, then co group, then sample,
@@ -390,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float f = r.f[j];
-          const float m = NOF ? r.okf : BITS ? (((__builtin_bit_cast(unsigned, r.f[0]) >> j) & 1u) ? r.okf : 0.f)
+          const float m = NOF ? (F16 ? r.okf * xscale : r.okf) : BITS ? (((__builtin_bit_cast(unsigned, r.f[0]) >> j) & 1u) ? r.okf : 0.f)
                                : RELU ? (f > 0.f ? r.okf : 0.f)
                                               : r.okf * (fc0 + fc1 * (f > 0.f ? 1.f : 0.f) + f * (fc2 + fc3 * f));
 #pragma unroll
@@ -402,11 +441,17 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
             const float e = v[2 * jj][c], o = v[2 * jj + 1][c];    // even / odd channel of the pair
-            const unsigned hb = pack_lo(e, o);                     // v_cvt_pk_bf16_f32 (RNE)
-            const float re = e - __builtin_bit_cast(float, hb << 16);
-            const float ro = o - __builtin_bit_cast(float, hb & 0xffff0000u);
-            h[jj] = hb;
-            l[jj] = pack_lo(re, ro);
+            if constexpr (F16) {
+              unsigned lo_;
+              h[jj] = split_f16(e, o, lo_);
+              l[jj] = lo_;
+            } else {
+              const unsigned hb = pack_lo(e, o);                   // v_cvt_pk_bf16_f32 (RNE)
+              const float re = e - __builtin_bit_cast(float, hb << 16);
+              const float ro = o - __builtin_bit_cast(float, hb & 0xffff0000u);
+              h[jj] = hb;
+              l[jj] = pack_lo(re, ro);
+            }
           }
           const int off = ((pix * 16 + xslot(q * 4 + c, pix)) << 4);
           *reinterpret_cast<u32x4*>(Xh + off) = h;
@@ -547,6 +592,19 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffff00, RS_FLAGS);
   };
   constexpr int Y_DROP = 0x7ffffff0;
+  // F16: relu' bit mask of the stored values (CMF_F_RELU_BITS layout of the next conv): per pixel ONE dword per sample = the 32
+  // channel bits of this wave's channel half, stored by lane s < 16 for sample slice*16 + s; the other lanes (and
+  // every lane when mask_out is NULL: zero records) store past the descriptor's range -- dropped, still counted by vmcnt
+  [[maybe_unused]] auto m_rsrc = [&](int np, int slice, int cog) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(a.mask_out ? a.mask_out : (void*)a.y) +
+                                 (unsigned long long)((long long)np * a.nc + slice * 16) * a.mask_np + (unsigned)(cog * 8 + cohalf * 4);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0,
+                                             a.mask_out ? 0x7fffff00 : 0, RS_FLAGS);
+  };
+  const int mvoff = lane < 16 ? lane * (int)a.mask_np : Y_DROP;
+  float ymax = 0.f;                                                // F16: running max of the stored values (-> *amax_out)
   auto r_rsrc = [&](int np, int slice, int cog, bool on) {         // words, for the inline-asm loads
     const float* base = a.r ? a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) + (long long)cog * 64 * r_co : a.y;
     const unsigned long long u = reinterpret_cast<unsigned long long>(base);
@@ -582,6 +640,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     }
   }
   auto cur_yrs = y_rsrc(np_, slice_, cog_);
+  auto cur_mrs = cur_yrs;
+  if constexpr (F16) cur_mrs = m_rsrc(np_, slice_, cog_);
   i32x4 nxt_rrs = r_rsrc(np_, slice_, cog_, n_items > 0);
   // Accumulator initial value of pixel p = residual, loaded straight into the accumulators by INLINE ASM with
   // hand-counted waits (wait_res below): hipcc's vmcnt for these loads also counted the interleaved stores'
@@ -630,6 +690,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     }
   };
   auto store_pixel = [&](const Item& it, int p) __attribute__((always_inline)) {
+    [[maybe_unused]] unsigned mbits = 0;
+    [[maybe_unused]] f32x4 vst[CW];
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       f32x4 v = acc[p][c];
@@ -639,9 +701,42 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         if constexpr (inplace) vo = on ? yvoff : Y_DROP;
         else v = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      v += bias[c];                                                // per-channel constant (primal bias)
+      if constexpr (F16) v = v * oscale + bias[c];                 // undo the operand scales (exact), then the bias
+      else v += bias[c];                                           // per-channel constant (primal bias)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, v), cur_yrs, vo,
                                              it.ypix + 4 * (((p / C::TW) * a.W + p % C::TW) * y_px + c * 16 * y_co), 0);
+      if constexpr (F16) {
+        vst[c] = v;
+        // inline asm on purpose (also the mask code below): written with builtins (fmaxf, __ballot + selects) this epilogue sent
+        // hipcc's register allocation from 251 VGPRs to 256 + 118 spilled
+        asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(ymax) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+      }
+    }
+    if constexpr (F16) {
+      // sign bits -> lanes: the ballot of register r of channel tile c holds, in its 16-bit quarter kq, the 16 channel bits of
+      // sample 4 kq + r.  SALU packs the quarters of the two tiles into one dword per sample (32 channels), v_writelane parks it
+      // in lane 4 kq + r: 8 v_cmp + 16 v_writelane + 24 SALU per pixel, one VGPR, no per-lane selects
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        unsigned alo, ahi, d;
+        asm volatile(
+            "v_cmp_lt_f32 vcc, 0, %4\n\t"
+            "s_mov_b32 %1, vcc_lo\n\t"
+            "s_mov_b32 %2, vcc_hi\n\t"
+            "v_cmp_lt_f32 vcc, 0, %5\n\t"
+            "s_pack_ll_b32_b16 %3, %1, vcc_lo\n\t"
+            "v_writelane_b32 %0, %3, %6\n\t"
+            "s_pack_hh_b32_b16 %3, %1, vcc_lo\n\t"
+            "v_writelane_b32 %0, %3, %7\n\t"
+            "s_pack_ll_b32_b16 %3, %2, vcc_hi\n\t"
+            "v_writelane_b32 %0, %3, %8\n\t"
+            "s_pack_hh_b32_b16 %3, %2, vcc_hi\n\t"
+            "v_writelane_b32 %0, %3, %9"
+            : "+v"(mbits), "=&s"(alo), "=&s"(ahi), "=&s"(d)
+            : "v"(vst[0][r]), "v"(vst[1][r]), "n"(r), "n"(4 + r), "n"(8 + r), "n"(12 + r)
+            : "vcc");
+      }
+      __builtin_amdgcn_raw_buffer_store_b32(mbits, cur_mrs, mvoff, (it.pix0 + (p / C::TW) * a.W + p % C::TW) * (a.cout / 8), 0);
     }
   };
   // Pixel p's residual has landed when at most N VMEM operations issued after it are outstanding.  The tail issues,
@@ -649,7 +744,9 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // (+ 2*CW*p of THIS chunk's tail when the item has a single chunk).
   auto wait_res = [&](int p, bool also_last) __attribute__((always_inline)) {
     static_assert(CW == 2 || CW == 1, "operand list below");
-    const int n = 2 * CW * (PW - 1 - p) + (also_last ? 2 * CW * p : 0);
+    constexpr int NT = 2 * CW + (F16 ? 1 : 0);                     // VMEM operations of one pixel's tail (F16: + the mask store)
+    const int n0 = NT * (PW - 1 - p) + (also_last ? NT * p : 0);
+    const int n = n0 > 63 ? 63 : n0;                               // vmcnt is a 6-bit field: waiting for more is always safe
     if constexpr (CW == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(acc[p][0]), "+v"(acc[p][1]) : "n"(n));
     else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(acc[p][0]) : "n"(n));
   };
@@ -745,14 +842,28 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         }
       }
 #endif
-      if (FIRST && s == 0) wait_res(p, false);
+      if (FIRST && s == 0) {
+        wait_res(p, false);
+        if constexpr (F16) {                                       // the accumulators hold (2^k xscale) x the result
+#pragma unroll
+          for (int c = 0; c < CW; ++c) acc[p][c] *= rscale;
+        }
+      }
 #pragma unroll
       for (int c = 0; c < CW; ++c) {
         // D[row = Jacobian column][col = output channel] = X-fragment (as A) x W-fragment (as B): each lane then
         // holds 4 CONSECUTIVE columns (rows kq*4 + r) of channel cl -> 16-byte stores / residual loads
-        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], al[s][c], acc[p][c], 0, 0, 0);
-        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
-        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
+        if constexpr (F16) {
+#define CMF_H8(v) __builtin_bit_cast(f16x8, v)                     /* the fragments are fp16 bit patterns */
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CMF_H8(bh[t % BD]), CMF_H8(al[s][c]), acc[p][c], 0, 0, 0);
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CMF_H8(bl[t % BD]), CMF_H8(ah[s][c]), acc[p][c], 0, 0, 0);
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(CMF_H8(bh[t % BD]), CMF_H8(ah[s][c]), acc[p][c], 0, 0, 0);
+#undef CMF_H8
+        } else {
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], al[s][c], acc[p][c], 0, 0, 0);
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
+          acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
+        }
       }
       if (LAST && s == KS - 1) {
         store_pixel(cur, p);
@@ -775,10 +886,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   for (int item = 0; item < n_items; ++item) {
     const bool has_next = item + 1 < n_items;
     auto nxt_yrs = cur_yrs;
+    auto nxt_mrs = cur_mrs;
     auto next_context = [&]() __attribute__((always_inline)) {                                   // derived right before the chunk that uses it
       int np, slice, cog;
       item_geom(has_next ? item + 1 : item, np, slice, cog, nxt);
       nxt_yrs = y_rsrc(np, slice, cog);
+      if constexpr (F16) nxt_mrs = m_rsrc(np, slice, cog);
       nxt_rrs = r_rsrc(np, slice, cog, has_next);                  // last item: zero records, nothing is fetched
     };
     // nchunks = 4 G (launcher precondition): chunks 4m, 4m+1, 4m+2 run two K-steps and park their centre pixels, chunk
@@ -807,14 +920,24 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     step(F{}, T{}, T{}, std::integral_constant<int, 0>{});
     cur = nxt;
     cur_yrs = nxt_yrs;
+    cur_mrs = nxt_mrs;
+  }
+  if constexpr (F16) {
+    if (a.amax_out) {                                              // values >= 0 order like their bit patterns
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ymax = __builtin_fmaxf(ymax, __shfl_xor(ymax, o, 64));
+      if (lane == 0 && n_items > 0) atomicMax(reinterpret_cast<int*>(a.amax_out), __builtin_bit_cast(int, ymax));
+    }
   }
 }
 
 // weight pre-split / pre-arrangement: out[cog][chunk][hl][s][cot 4][kq][co 16][8] bf16
 // transpose: `w` is the LAYER's weight [cin][cout][3][3] and the pack is of its adjoint operator -- channels swapped, taps
 // flipped -- [cout][cin][tap] = w[ci][co][8 - tap]
+// f16 != 0 (cmf_pack_weight_f16x3): fp16 halves of w 2^k, the scale read from the trailer pack_f16_scale_kernel wrote behind the
+// `total` elements
 __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int cout,
-                                          int cin, long long total, int transpose) {
+                                          int cin, long long total, int transpose, int f16) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int j = (int)(i & 7), col = (int)((i >> 3) & 15), kq = (int)((i >> 7) & 3), cot = (int)((i >> 9) & 3);
@@ -835,20 +958,47 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned 
   }
   float v = 0.f;
   if (co < cout && tap < 9) v = transpose ? w[((long long)ci * cout + co) * 9 + (8 - tap)] : w[((long long)co * cin + ci) * 9 + tap];
+  if (f16) {
+    v *= reinterpret_cast<const float*>(out + total)[0];          // exact: a power of two
+    const _Float16 h = (_Float16)v;
+    const _Float16 r = hl ? (_Float16)(v - (float)h) : h;
+    out[i] = __builtin_bit_cast(unsigned short, r);
+    return;
+  }
   const __bf16 h = (__bf16)v;
   const float hf = (float)h;
   const __bf16 r = hl ? (__bf16)(v - hf) : h;
   out[i] = __builtin_bit_cast(unsigned short, r);
 }
 
-template <int COT, int PXW, int MODE>
+// trailer {2^k, 2^-k, 0, 0} with max |w| 2^k in [2^11, 2^12): one workgroup, no host synchronisation
+__global__ __launch_bounds__(1024) void pack_f16_scale_kernel(const float* __restrict__ w, long long n, float* __restrict__ trailer) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    const int ex = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);          // m = f 2^(ex - 126), f in [0.5, 1)
+    int k = (ex == 0 || ex == 255) ? 0 : 12 - (ex - 126);
+    k = k < -60 ? -60 : k > 60 ? 60 : k;
+    trailer[0] = pow2i(k);
+    trailer[1] = pow2i(-k);
+    trailer[2] = trailer[3] = 0.f;
+  }
+}
+
+template <int COT, int PXW, int MODE, bool F16 = false>
 int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   using C = BCfg<COT, PXW>;
   const int tiles_x = cmf_ceil_div(a.W, C::TW), tiles = tiles_x * cmf_ceil_div(a.H, C::TH);
   const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
-  auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE>;
+  auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE, F16>;
   constexpr int lds = C::LDS_BYTES;
   if (hipError_t e = cmf_set_dynamic_lds((const void*)k, lds); e != hipSuccess) return (int)e;   // per device (runtime.hip)
   const int n_cu = cmf_device_cus();
@@ -889,7 +1039,22 @@ extern "C" int cmf_pack_weight_bf16x3_t(const float* w, void* out, int cout, int
   if (!out) return 0;
   if (!w) return CMF_EINVAL;
   hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     w, (unsigned short*)out, cout, cin, total, transpose ? 1 : 0);
+                     w, (unsigned short*)out, cout, cin, total, transpose ? 1 : 0, 0);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cmf_pack_weight_f16x3(const float* w, void* out, int cout, int cin, int transpose, long long* out_bytes, void* stream) {
+  if (cout <= 0 || cin <= 0 || cin % 8) return CMF_EINVAL;
+  const long long total = (long long)((cout + 63) / 64) * (cin / 8) * 2 * 3 * 4 * 4 * 16 * 8;   // fp16 elements, then the trailer
+  if (out_bytes) *out_bytes = total * 2 + 16;
+  if (!out) return 0;
+  if (!w || (uintptr_t)out % 16) return CMF_EINVAL;
+  hipLaunchKernelGGL(pack_f16_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)cout * cin * 9,
+                     reinterpret_cast<float*>((unsigned short*)out + total));
+  CMF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     w, (unsigned short*)out, cout, cin, total, transpose ? 1 : 0, 1);
   CMF_LAUNCH_CHECK();
   return 0;
 }
@@ -937,4 +1102,27 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
     return t14 ? launch_cot<7>(b, s) : launch_cot<4>(b, s);
   }
   return t14 ? launch_cot<7>(a, s) : launch_cot<4>(a, s);
+}
+
+extern "C" int cmf_conv_tangent_f16x3(const cmf_conv_tangent_args* ap, void* stream) {
+  if (!ap) return CMF_EINVAL;
+  const cmf_conv_tangent_args& a = *ap;
+  if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
+  if (a.taps != 9 || a.cin % 32 || a.nc <= 0 || a.nc % 16 || a.cout % 64) return CMF_EINVAL;
+  if (a.fmode != CMF_F_SELF_RELU || a.fo) return CMF_EINVAL;      // the primal pass: the input's own relu, no output factor
+  if (a.mask_out && (a.mask_np % 4 || (uintptr_t)a.mask_out % 4 || a.mask_np < (long long)a.H * a.W * (a.cout / 8) ||
+                     16 * a.mask_np >= 0x7fffff00LL))
+    return CMF_EINVAL;
+  if ((a.x_np | a.x_ci | a.x_px | a.x_sl | a.y_sl | a.r_sl) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
+  if ((a.y_np | a.y_co | a.y_px) % 4 || ((uintptr_t)a.y % 16)) return CMF_EINVAL;
+  if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;
+  const long long HW = (long long)a.H * a.W;
+  if (!fits_int((a.cin + 8) * a.x_ci + HW * a.x_px + a.nc) || !fits_int((a.cout + 64) * a.y_co + HW * a.y_px + a.nc + 64) ||
+      (a.r && !fits_int((a.cout + 64) * a.r_co + HW * a.r_px + a.nc)) || HW > (1 << 24))
+    return CMF_ERANGE;
+  const bool t14 = a.W % 14 == 0 && a.H % 2 == 0, t8 = a.W % 8 == 0 && a.H % 4 == 0;
+  if (!(t14 || t8)) return CMF_EINVAL;
+  if (a.bias && a.cout > 64) return CMF_EINVAL;                 // the per-channel constants are fetched once per launch
+  hipStream_t s = (hipStream_t)stream;
+  return t14 ? launch<4, 7, 2, true>(a, s) : launch<4, 4, 2, true>(a, s);
 }

@@ -516,3 +516,31 @@ int cmf_elbo_combine(const float* low, const float* logdet, const float* rec, co
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out[0] = max(out[0], max |x|): the input-range word of cmf_conv_tangent_f16x3 (amax_in) for a tensor no conv of that
+// family produced (the coupler's first activation).  Non-negative floats order like their bit patterns: integer atomicMax.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  float m = 0.f;
+  const long long n4 = n >> 2, stride = (long long)gridDim.x * 256;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = x4[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(out), __builtin_bit_cast(int, m));
+}
+}  // namespace
+
+extern "C" int cmf_absmax(const float* x, long long n, float* out, void* stream) {
+  if (!x || !out || n <= 0 || (uintptr_t)x % 16) return CMF_EINVAL;
+  const long long blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}

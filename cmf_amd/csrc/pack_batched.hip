@@ -25,7 +25,7 @@ __device__ __forceinline__ float pack_f32_elem(const cmf_pack_desc& e, long long
 }
 
 // cout / cin here are the PACKED operator's (the adjoint's when transpose: the caller swaps them, like cmf_pack_weight_bf16x3_t's)
-__device__ __forceinline__ unsigned short pack_bf16x3_elem(const cmf_pack_desc& e, long long i) {
+__device__ __forceinline__ unsigned short pack_bf16x3_elem(const cmf_pack_desc& e, long long i, float scale) {
   const int j = (int)(i & 7), col = (int)((i >> 3) & 15), kq = (int)((i >> 7) & 3), cot = (int)((i >> 9) & 3);
   long long t = i >> 11;
   const int s = (int)(t % 3);
@@ -43,6 +43,12 @@ __device__ __forceinline__ unsigned short pack_bf16x3_elem(const cmf_pack_desc& 
   float v = 0.f;
   if (co < e.cout && tap < 9)
     v = e.transpose ? e.w[((long long)ci * e.cout + co) * 9 + (8 - tap)] : e.w[((long long)co * e.cin + ci) * 9 + tap];
+  if (e.kind == 2) {                                   // cmf_pack_weight_f16x3: fp16 halves of w 2^k
+    v *= scale;
+    const _Float16 h = (_Float16)v;
+    const _Float16 r = hl ? (_Float16)(v - (float)h) : h;
+    return __builtin_bit_cast(unsigned short, r);
+  }
   const __bf16 h = (__bf16)v;
   const __bf16 r = hl ? (__bf16)(v - (float)h) : h;
   return __builtin_bit_cast(unsigned short, r);
@@ -56,7 +62,31 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const cmf_pack_desc* 
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < e.total; i += stride) out[i] = pack_f32_elem(e, i);
   } else {
     unsigned short* out = reinterpret_cast<unsigned short*>(e.out);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < e.total; i += stride) out[i] = pack_bf16x3_elem(e, i);
+    float scale = 1.f;
+    if (e.kind == 2) {
+      // fp16 pack: max |w| 2^k in [2^11, 2^12) (pack_f16_scale_kernel's rule).  EVERY block takes the maximum of the whole weight
+      // itself (147 KB for a 64 -> 64 layer, L2-resident): no hand-off between blocks; block 0 writes the 16-byte trailer.
+      __shared__ float red[4];
+      const long long n = (long long)e.cout * e.cin * 9;
+      float m = 0.f;
+      for (long long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(e.w[i]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+      __syncthreads();
+      m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      const int ex = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
+      int k = (ex == 0 || ex == 255) ? 0 : 12 - (ex - 126);
+      k = k < -60 ? -60 : k > 60 ? 60 : k;
+      scale = __builtin_bit_cast(float, (unsigned)(k + 127) << 23);
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float* tr = reinterpret_cast<float*>(out + e.total);
+        tr[0] = scale;
+        tr[1] = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+        tr[2] = tr[3] = 0.f;
+      }
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < e.total; i += stride) out[i] = pack_bf16x3_elem(e, i, scale);
   }
 }
 

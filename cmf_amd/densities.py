@@ -267,6 +267,18 @@ class DataParallelDensity(nn.Module):
 # --------------------------------------------------------------------------------------------------
 
 
+def _scoped(fn):
+    """Run a FlowProgram method under its head's KernelConfig (``head.kernels``): which arithmetic the convolution kernels use is
+    an attribute of the head, carried by a thread-local scope -- not process state (one thread per GPU, re-entrant)."""
+    import functools
+
+    @functools.wraps(fn)
+    def run(self, *args, **kwargs):
+        with E.scope(self.head.kernels):
+            return fn(self, *args, **kwargs)
+    return run
+
+
 class FlowProgram:
     """Static plan of the layers between a NonSquareHeadDensity and the Gaussian at the bottom of its
     low-dimensional prior; replaces ``_traverse_backward`` / ``_set_flow_and_jvp_stacks``
@@ -276,6 +288,7 @@ class FlowProgram:
     TANGENT_BUDGET = 160 << 30                      # of the 288 GB; C3 at B = 512 needs ~20 GB, C5 at B = 256 ~45 GB
 
     def __init__(self, head):
+        self.head = head
         self.layers = []
         node = head.prior
         while not isinstance(node, NonSquareTailDensity):
@@ -338,6 +351,7 @@ class FlowProgram:
         return 4 * nc * (total + (worst if recompute else 0)) + self.tangent_bytes_per_sample(nc)
 
     # -- x -> (z_low, low_dim_elbo, earliest latent) ----------------------------------------------
+    @_scoped
     def encode(self, x):
         B = x.shape[0]
         h = x.detach().clone().contiguous()
@@ -361,6 +375,7 @@ class FlowProgram:
         self.gaussian.logprob_accumulate(u, lj)
         return z_low, lj, u
 
+    @_scoped
     def encode_nested(self, x):
         """``encode`` that also rebuilds the reference's NESTED ``prior-dict`` (non_square.py:126-129 returns the dict of
         ``self.prior.elbo(x)``: one level per module of the chain -- exact.py:23-30 ``{"elbo", "bijection-info": {"z",
@@ -414,6 +429,7 @@ class FlowProgram:
         return z_low, low_elbo, u, node
 
     # -- z_low -> (x_hat, J) ----------------------------------------------------------------------
+    @_scoped
     def decode(self, z_low, tangents=True, eps=None):
         B, dev = z_low.shape[0], z_low.device
         N = int(np.prod(self.tail.x_shape))
@@ -438,6 +454,7 @@ class FlowProgram:
         return z, T
 
     # -- reverse sweep: cotangents in data space -> J^T w in latent space ---------------------------
+    @_scoped
     def vjp(self, z_low, Wd):
         """``Wd``: (B, D, S) cotangent columns over the flattened data space; returns (x_hat, J^T Wd) with J^T Wd of shape
         (B, d, S) -- the vjp of ``flow_forward`` (non_square.py:190-201) for S directions at once.  A primal decode keeps
@@ -472,6 +489,7 @@ class FlowProgram:
         return z, out.to_dense(S).contiguous()
 
     # -- training: decode with saved state, and its backward -------------------------------
+    @_scoped
     def decode_train(self, z_low, tangents=True, keep=True, eps=None, nc=None, nc_hint=None):
         """``decode(z_low, tangents)`` keeping every coupling layer's context (``keep=False``: only its inputs, the rest is
         recomputed layer by layer in ``decode_backward``); returns (x_hat, T, ctx).  ``eps`` (B, d, n): the sweep carries the n
@@ -500,6 +518,7 @@ class FlowProgram:
                 ctx.append(None)
         return z, T, ctx
 
+    @_scoped
     def decode_tangents_from_ctx(self, ctx, eps=None, nc=None, save=False):
         """A tangent sweep over the PRIMAL contexts of ``decode_train(z_low, tangents=False)``: returns (T, ctx') where ctx' is
         the context list ``decode_backward`` consumes when ``save`` (else None).  Layers are walked like ``decode_train``."""
@@ -523,6 +542,7 @@ class FlowProgram:
                 out.append(None)
         return T, (out if save else None)
 
+    @_scoped
     def decode_backward(self, ctx, Ct, dx, grads):
         """Backward of ``decode_train``: ``Ct`` = cotangent of the Jacobian stack at the head (e.g. ``engine.gram_backward``),
         ``dx`` = cotangent of x_hat.  Accumulates parameter gradients into ``grads`` and returns the cotangent of z_low (B, d)."""
@@ -541,6 +561,7 @@ class FlowProgram:
                 dx = m.encode(dx)                                  # x[r] = z[z2x[r]]  ->  dz = dx[x2z]
         return E.gather_primal(dx.reshape(B, -1), self.tail.gather_index(dev), self.d)
 
+    @_scoped
     def encode_train(self, x):
         """``encode`` keeping every layer's context: returns (z_low, low_dim_elbo, u, ctx, prior_ctx)."""
         B = x.shape[0]
@@ -572,6 +593,7 @@ class FlowProgram:
         self.gaussian.logprob_accumulate(u, lj)
         return z_low, lj, u, ctx, pctx
 
+    @_scoped
     def prior_backward(self, pctx, u, dlow, grads):
         """Backward of the low-dimensional prior chain: ``dlow`` (B,) = cotangent of low_dim_elbo = log N(u) + sum log-jac;
         returns the cotangent of z_low (B, d) and accumulates the prior flows' parameter gradients."""
@@ -586,6 +608,7 @@ class FlowProgram:
                 m.encode_backward_(du, c, grads, dlj=dlow)
         return du
 
+    @_scoped
     def encode_backward(self, ctx, dz_low, grads):
         """Backward of the encode chain above the base: cotangent of z_low -> parameter gradients (and the unused cotangent of x)."""
         B, dev = dz_low.shape[0], dz_low.device
@@ -602,6 +625,7 @@ class FlowProgram:
         return dh
 
     # -- latent noise -> z_low (sampling) ----------------------------------------------------------
+    @_scoped
     def prior_inverse(self, u):
         z = u.detach().clone().contiguous()
         for m in reversed(self.prior):
@@ -716,6 +740,9 @@ class NonSquareHeadDensity(Density):
         if log_jacobian_method not in self._VALID_LOG_JACOBIAN_METHODS:
             raise ValueError(f"{log_jacobian_method} not a valid Jacobian calculation method")
         self.log_jacobian_method = log_jacobian_method
+        #: arithmetic of this head's convolution kernels (engine.KernelConfig: tangent "bf16x3" | "f32", primal "f16x3" | "f32" |
+        #: "bf16x3"); a plain attribute -- not a parameter or buffer, not in the state dict
+        self.kernels = E.KernelConfig()
         self._program = None
         self.last_gram = None
 

@@ -12,6 +12,7 @@ Layouts
                                    convolution whose "pixels" are the batch samples
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -78,24 +79,81 @@ class KernelTimer:
                 "bytes": sum(r[2] for r in self.records)}
 
 
-TIMER = None   # set to a KernelTimer by bench.py
+class KernelConfig:
+    """Which arithmetic the convolution kernels of a head run in (an attribute of ``NonSquareHeadDensity``: ``head.kernels``;
+    every ``FlowProgram`` method runs inside ``scope(head.kernels)``, so two heads -- or two threads -- may differ).
 
-#: arithmetic of the 3x3 tangent convolutions: "bf16x3" = split-precision bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32
-#: accumulate; fp32-grade result), "f32" = exact fp32 MFMA.  Layers the bf16x3 kernel does not cover
-#: (1x1, cin % 8 != 0, widths other than 14 / 28) always use the fp32 kernel.
-TANGENT_PRECISION = "bf16x3"
+    tangent  3x3 hidden TANGENT convolutions (all d Jacobian columns), their transposes and weight gradients:
+             "bf16x3" = split-precision bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32 accumulate; fp32-grade on the tangents: errors
+             average over K = 576), "f32" = exact fp32 MFMA.  Layers the split kernel does not cover (1x1, cin % 32 != 0, widths
+             other than multiples of 14 / 8) always use the fp32 kernel.
+    primal   hidden 3x3 PRIMAL convolutions of a ResNet coupler (16 samples in the column slots of the tangent kernels).  The
+             relu masks of the Jacobian are taken from these activations, and a pre-activation that lands on the other side of
+             zero than in the reference flips a mask, so this arithmetic has to be fp32-grade PER PRODUCT:
+             "f16x3" (default) = fp16 split, 11 + 11 significant bits with exact power-of-two operand scales (~2^-22 per product:
+             as few mask flips as exact fp32 products, profiles/r04_primal_precision_study.txt) at the bf16 MFMA rate;
+             "f32" = exact fp32 MFMA (2.8x slower); "bf16x3" = bf16 split (~2^-16: ~15x more mask flips, median per-sample
+             log-det / g_ij error 3e-6 / 1.4e-5 instead of 1e-6 / 2e-7 -- kept as an experiment, never the default)."""
+    __slots__ = ("tangent", "primal")
+
+    def __init__(self, tangent="bf16x3", primal="f16x3"):
+        assert tangent in ("bf16x3", "f32") and primal in ("f16x3", "f32", "bf16x3")
+        self.tangent, self.primal = tangent, primal
+
+    def __repr__(self):
+        return f"KernelConfig(tangent={self.tangent!r}, primal={self.primal!r})"
 
 
-#: arithmetic of the PRIMAL hidden 3x3 convolutions of a ResNet coupler.  They run through the tangent conv kernels with 16
-#: samples in the column slots; "f32" = the fp32-MFMA kernel (exact fp32 products), "bf16x3" = the split-precision kernel
-#: (2.5x faster, ~1e-6 relative).  The default is "f32": the relu masks of the Jacobian are taken from these activations,
-#: and a pre-activation that lands on the other side of zero than in the reference flips a mask -- with bf16x3 primals the
-#: median per-sample log-det / g_ij error against the CPU oracle was 9e-6 / 1.8e-5 instead of 3e-7 / 4e-7.
-PRIMAL_PRECISION = "f32"
+_DEFAULT_CONFIG = KernelConfig()
+_tls = threading.local()
+
+
+def cfg():
+    """The calling thread's current KernelConfig (the innermost ``scope``), or the defaults."""
+    stack = getattr(_tls, "cfg", None)
+    return stack[-1] if stack else _DEFAULT_CONFIG
+
+
+class scope:
+    """``with scope(config):`` -- kernels launched by THIS thread inside the block use ``config`` (re-entrant, nestable)."""
+
+    def __init__(self, config=None, **kw):
+        self.config = config if config is not None else KernelConfig(**{**{"tangent": cfg().tangent, "primal": cfg().primal}, **kw})
+
+    def __enter__(self):
+        if not hasattr(_tls, "cfg"):
+            _tls.cfg = []
+        _tls.cfg.append(self.config)
+        return self.config
+
+    def __exit__(self, *exc):
+        _tls.cfg.pop()
+        return False
+
+
+def _timer():
+    return getattr(_tls, "timer", None)
+
+
+class timing:
+    """``with timing(select) as t:`` -- launches of THIS thread whose family name ``select`` accepts are bracketed by HIP
+    events on the launch stream; ``t.by_name()`` / ``t.summary()`` synchronise once (bench.py's roofline / stages legs)."""
+
+    def __init__(self, select):
+        self.timer = KernelTimer(select)
+
+    def __enter__(self):
+        self.prev = _timer()
+        _tls.timer = self.timer
+        return self.timer
+
+    def __exit__(self, *exc):
+        _tls.timer = self.prev
+        return False
 
 
 def _use_bf16x3(taps, cin, W, transpose, H=None, cout=64):
-    return TANGENT_PRECISION == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
+    return cfg().tangent == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
 
 
 def _shape_ok_bf16x3(taps, cin, W, transpose, H=None, cout=64):
@@ -165,8 +223,11 @@ class _PackCache:
         self.generation += 1
 
     def get(self, weight, taps, transpose=False, bf16x3=False):
+        """``bf16x3``: False = cmf_pack_weight's floats, True / "bf16x3" = the split-precision pack, "f16x3" = the fp16 pack
+        (scaled by a power of two, 16-byte trailer)."""
         import weakref
-        key = (id(weight), bool(transpose), bool(bf16x3))
+        bf16x3 = {False: 0, True: 1, "bf16x3": 1, "f16x3": 2, 0: 0, 1: 1, 2: 2}[bf16x3]      # = cmf_pack_desc.kind
+        key = (id(weight), bool(transpose), bf16x3)
         ver = (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape), self.generation)
         hit = self._store.get(key)
         if hit is not None and hit[0]() is weight and hit[1] == ver:
@@ -189,9 +250,11 @@ class _PackCache:
         if bf16x3:
             if transpose:                                  # the adjoint operator: channels swapped, taps flipped -- by the pack kernel
                 cout, cin = cin, cout
-            _lib.check(lib.cmf_pack_weight_bf16x3_t(None, None, cout, cin, int(transpose), C.byref(n), None), "pack size")
+            fn, what = ((lib.cmf_pack_weight_bf16x3_t, "cmf_pack_weight_bf16x3_t") if bf16x3 == 1 else
+                        (lib.cmf_pack_weight_f16x3, "cmf_pack_weight_f16x3"))
+            _lib.check(fn(None, None, cout, cin, int(transpose), C.byref(n), None), "pack size")
             out = buf(n.value, torch.uint8)
-            _lib.check(lib.cmf_pack_weight_bf16x3_t(_p(w), _p(out), cout, cin, int(transpose), None, _stream()), "cmf_pack_weight_bf16x3_t")
+            _lib.check(fn(_p(w), _p(out), cout, cin, int(transpose), None, _stream()), what)
         else:
             _lib.check(lib.cmf_pack_weight(None, None, cout, cin, taps, int(transpose), C.byref(n), None), "pack size")
             out = buf(4 * n.value, torch.float32)
@@ -229,8 +292,9 @@ class _PackCache:
                 cout, cin = int(w.shape[0]), int(w.shape[1])
                 if bf16x3 and transpose:
                     cout, cin = cin, cout
-                arr[i] = (w.data_ptr(), out.data_ptr(), out.numel() * out.element_size() // (2 if bf16x3 else 4), cout, cin, taps,
-                          int(transpose), int(bf16x3), 0)
+                total = out.numel() * out.element_size()
+                total = (total - 16) // 2 if bf16x3 == 2 else total // (2 if bf16x3 else 4)     # kind 2: 16-byte trailer
+                arr[i] = (w.data_ptr(), out.data_ptr(), total, cout, cin, taps, int(transpose), int(bf16x3), 0)
             table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
             self._tables[device] = (sig, table)
         _lib.check(_lib.load().cmf_pack_weights_batched(_p(table), len(todo), _stream()), "cmf_pack_weights_batched")
@@ -265,9 +329,10 @@ def conv_primal(x_ptr_t, x_off, x_b, x_c, x_px, weight, taps, bias, y, y_b, y_c,
 def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_px, np_, cin, cout, H, W, nc,
                  fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, res_t=None, transpose=False, bias=None, f_group=1,
                  x_sl=16, y_sl=16, precision=None, y_off=0, res_off=0, fo=None, fo_np=0, fo_co=0, fo_px=0, fomode=F_NONE,
-                 mask_out=None, mask_np=0):
+                 mask_out=None, mask_np=0, amax_in=None, amax_out=None):
     """``fo`` = OUTPUT-side factor (reverse sweep, fp32 kernel only); ``y_off`` / ``res_off`` = element offsets into
-    ``y_t`` / ``res_t`` (in-place accumulation into a strided view of a larger tensor)."""
+    ``y_t`` / ``res_t`` (in-place accumulation into a strided view of a larger tensor).  ``precision`` "f16x3": the fp16 split
+    kernel of the primal pass (``amax_in`` / ``amax_out``: one-float device tensors, the input-range chain)."""
     lib = _lib.load()
     a = ConvTangentArgs()
     a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
@@ -277,25 +342,31 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     obits = isinstance(fo, BitMask)
     # ... or with the residual IN PLACE (res_t is y_t at the same offset: y <- y + mask . conv(x), the reverse sweep's skip connection)
     inplace = res_t is not None and res_t.data_ptr() == y_t.data_ptr() and int(res_off) == int(y_off)
-    split = ((precision or TANGENT_PRECISION) == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
+    precision = precision or cfg().tangent
+    split = (precision == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
              and ((fmode != F_NONE and fo is None) or
                   (fmode == F_NONE and (fo is None or (obits and (res_t is None or inplace) and cout % 64 == 0)))))
+    f16 = (precision == "f16x3" and fmode == F_SELF_RELU and fo is None and not transpose and cout % 64 == 0
+           and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout))
     assert not obits or split, "bit-mask output factors are applied by the split-precision kernel only"
     if obits:
         fo, fo_np, fo_co, fo_px, fomode = fo.data, fo.np_bytes, 0, 0, F_RELU_BITS
-    a.w = _p(PACKS.get(weight, taps, transpose, bf16x3=split))
+    a.w = _p(PACKS.get(weight, taps, transpose, bf16x3="f16x3" if f16 else split))
     a.y = C.c_void_p(y_t.data_ptr() + 4 * int(y_off)); a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
     a.r = None if res_t is None else C.c_void_p(res_t.data_ptr() + 4 * int(res_off))
     a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
     a.fo = _p(fo); a.fo_np, a.fo_co, a.fo_px, a.fomode = int(fo_np), int(fo_co), int(fo_px), int(fomode)
     a.mask_out = _p(mask_out); a.mask_np = int(mask_np)
     assert not (fmode == F_RELU_BITS and not split), "bit-mask factors are read by the split-precision kernel only"
-    assert not (mask_out is not None and split), "sign bits are written by the fp32 kernel only"
+    assert not (mask_out is not None and split), "sign bits are written by the fp32 and the fp16-split kernels only"
+    a.amax_in, a.amax_out = (_p(amax_in), _p(amax_out)) if f16 else (None, None)
     a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), int(taps)
     a.bias = _p(bias); a.f_group = int(f_group)
     a.x_sl, a.y_sl, a.r_sl = int(x_sl), int(y_sl), int(y_sl)
-    fn, what = (lib.cmf_conv_tangent_bf16x3, "cmf_conv_tangent_bf16x3") if split else (lib.cmf_conv_tangent, "cmf_conv_tangent")
+    fn, what = ((lib.cmf_conv_tangent_f16x3, "cmf_conv_tangent_f16x3") if f16 else
+                (lib.cmf_conv_tangent_bf16x3, "cmf_conv_tangent_bf16x3") if split else (lib.cmf_conv_tangent, "cmf_conv_tangent"))
     launch = lambda: _lib.check(fn(C.byref(a), _stream()), what)
+    TIMER = _timer()
     if TIMER is None:
         return launch()
     # algorithmic work of this launch: 2*cin*cout*taps FLOP per output pixel and Jacobian column; every input,
@@ -331,12 +402,13 @@ def conv_tangent_wgrad(x_t, x_off, x_np, x_ci, x_px, gy_t, gy_off, y_np, y_co, y
         ws = _WGRAD_WS[key] = torch.empty(need // 4, dtype=torch.float32, device=x_t.device)
     gy = C.c_void_p(gy_t.data_ptr() + 4 * int(gy_off))
     # split-precision kernel (operands shared through LDS) where the forward convs use one: whole 64-channel blocks, column pairs
-    split = ((precision or TANGENT_PRECISION) == "bf16x3" and taps == 9 and cin % 64 == 0 and cout % 64 == 0 and nc % 32 == 0
+    split = ((precision or cfg().tangent) == "bf16x3" and taps == 9 and cin % 64 == 0 and cout % 64 == 0 and nc % 32 == 0
              and fmode in (F_NONE, F_RELU, F_SELF_RELU, F_RELU_BITS) and f_group <= 1)
     assert not fbits or split, "bit-mask factors are read by the split-precision weight-gradient kernel only"
     fn, what = (lib.cmf_conv_tangent_wgrad_bf16x3, "cmf_conv_tangent_wgrad_bf16x3") if split else \
                (lib.cmf_conv_tangent_wgrad, "cmf_conv_tangent_wgrad")
     launch = lambda: _lib.check(fn(C.byref(a), gy, _p(dw), _p(ws), need, _stream()), what)
+    TIMER = _timer()
     if TIMER is None:
         return launch()
     px = float(H) * W * nc * np_
@@ -351,6 +423,11 @@ def primal_regroup(t, to_grouped):
     out = torch.empty(t.numel(), dtype=torch.float32, device=t.device)
     _lib.check(_lib.load().cmf_primal_regroup(_p(t), _p(out), B, N, int(to_grouped), _stream()), "cmf_primal_regroup")
     return out
+
+
+def absmax(t, out):
+    """out[0] = max(out[0], max |t|) for a flat fp32 tensor (the input-range word of the fp16-split primal convs)."""
+    _lib.check(_lib.load().cmf_absmax(_p(t), t.numel(), _p(out), _stream()), "cmf_absmax")
 
 
 def gather_primal(src, idx, n_out, out=None):
@@ -392,6 +469,7 @@ def acl_tangent(T, YT, z, y, g, maps):
     launch = lambda: _lib.check(_lib.load().cmf_acl_tangent(_p(T.data), T.t_b, T.t_r, _p(YT.data), YT.t_b, YT.t_r, T.nc, _p(z2),
                                                             z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]), _p(maps["si"]),
                                                             _p(maps["ti"]), maps["n"], B, _stream()), "cmf_acl_tangent")
+    TIMER = _timer()
     if TIMER is None:
         return launch()
     # coupling pass, per modified element: tangent rows v, s-dot, t-dot in (3 x NC floats), one row out, 5 scalars
@@ -500,6 +578,7 @@ def gram_cholesky(T, d, max_attempts=6, eps0=1e-6):
     launch = lambda: _lib.check(lib.cmf_gram_cholesky(_p(T.data), T.t_b, T.t_r, T.N, T.nc, d, T.B, _p(r.jtj), _p(r.logdet),
                                                       _p(r.l1_off), _p(r.l1_diag), _p(r.info), _p(r.fail), _stream()),
                                 "cmf_gram_cholesky")
+    TIMER = _timer()
     if TIMER is None:
         launch()
     else:                                          # 2 D d^2 (+ d^3/3) FLOP and (D NC + d^2 + 3) 4 B per sample
@@ -700,6 +779,7 @@ def mlp_coupler(net, z, T, view, maps, decode, lj=None, ncols=None):
     a.lj = _p(lj)
     a.ncols = int(ncols) if (T is not None and ncols is not None) else 15
     launch = lambda: _lib.check(_lib.load().cmf_mlp_coupler(C.byref(a), _stream()), "cmf_mlp_coupler")
+    TIMER = _timer()
     if TIMER is None:
         return launch()
     # algorithmic work: 2 in out FLOP per layer and column (1 primal + ncols tangents, or 1 per sample in primal mode)
@@ -951,20 +1031,20 @@ class ActList(list):
 def train_acts_mode(net, view, B, T=None):
     """``need_acts`` for a training forward: "train" (ActList) where every consumer can work from bit masks and grouped floats,
     else True (per-sample float activations)."""
-    if net.kind != "resnet" or B % 32 or PRIMAL_PRECISION != "f32":
+    if net.kind != "resnet" or B % 32 or cfg().primal == "bf16x3":        # (the bf16 split kernel writes no bit masks)
         return True
     conv0 = _resnet_parts(net)[0]
     hid, H, W = conv0.out_channels, view.geom.H, view.geom.W
     if hid % 64 or not _shape_ok_bf16x3(9, hid, W, True, H, hid):
         return True
-    if T is not None and (TANGENT_PRECISION != "bf16x3" or T.nc % 32):
+    if T is not None and (cfg().tangent != "bf16x3" or T.nc % 32):
         return True
     return "train"
 
 
 def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts):
     """Hidden 3x3 convs of the primal ResNet through the TANGENT conv kernels: the 16 column slots carry 16 samples (relu
-    applied elementwise on load, bias as per-channel constant); ``PRIMAL_PRECISION`` picks the kernel.
+    applied elementwise on load, bias as per-channel constant); ``cfg().primal`` picks the kernel (KernelConfig).
     need_acts: False (encode pass, sampling), True (float activations in the standard layout: fp32 tangent path, reverse
     sweep) or "bits" (the split-precision tangent pass follows: the fp32 kernel writes relu' bit masks next to each
     activation, 1/32 of the bytes, and nothing is regrouped but the last activation, which the 1x1 conv reads as floats)."""
@@ -972,17 +1052,28 @@ def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts
     pn = (hid * HW * 16, HW * 16, 16)                       # (np, chan, px) strides of a grouped tensor
     new = lambda: torch.empty(G * hid * HW * 16, dtype=torch.float32, device=dev)
     train = need_acts == "train"                          # ActList: the "bits" form + the grouped floats
-    bits = (need_acts == "bits" or train) and PRIMAL_PRECISION == "f32" and hid % 16 == 0
+    prec = cfg().primal
+    if prec == "f16x3" and hid % 64:
+        prec = "f32"                                        # the fp16 split kernel works on whole 64-channel groups
+    bits = (need_acts == "bits" or train) and prec != "bf16x3" and hid % 16 == 0
     a = primal_regroup(a0, True)
     acts, masks = [a], []
-    for blk in blocks:
+    # fp16 split: the input-range chain.  Word i = max |activation i| (word 0 by a reduction over a_0, the others raised by the
+    # conv that stores the activation); a conv scales its input by the power of two that puts that maximum in [2^13, 2^14)
+    # before the fp16 split.  A residual block's output is read by the next block's conv1 only, its conv1 output by conv2 only.
+    rng = None
+    if prec == "f16x3":
+        rng = torch.zeros(2 * len(blocks) + 1, dtype=torch.float32, device=dev)
+        absmax(a, rng[0:1])
+    ax = lambda i: dict(amax_in=rng[i:i + 1], amax_out=rng[i + 1:i + 2]) if rng is not None else {}
+    for k, blk in enumerate(blocks):
         c1, a2 = new(), new()
         m1, m2 = (BitMask(B, HW, hid, dev), BitMask(B, HW, hid, dev)) if bits else (None, None)
         mo = lambda m: dict(mask_out=m.data, mask_np=m.np_bytes) if m is not None else {}
         conv_tangent(a, 0, *pn, blk.conv1.weight, 9, c1, *pn, G, hid, hid, H, W, 16, fmode=F_SELF_RELU, bias=blk.conv1.bias,
-                     precision=PRIMAL_PRECISION, **mo(m1))
+                     precision=prec, **mo(m1), **ax(2 * k))
         conv_tangent(c1, 0, *pn, blk.conv2.weight, 9, a2, *pn, G, hid, hid, H, W, 16, fmode=F_SELF_RELU, bias=blk.conv2.bias,
-                     res_t=a, precision=PRIMAL_PRECISION, **mo(m2))
+                     res_t=a, precision=prec, **mo(m2), **ax(2 * k + 1))
         acts += [c1, a2]
         masks += [m1, m2]
         a = a2
@@ -1136,7 +1227,7 @@ def net_cotangent(net, YC, view, acts, Ct, saved=None, grads=None, cross=None):
         # The hidden 3x3 transposed convs run on the split-precision kernel when the forward ones do: no input factor, relu' as
         # an output BIT MASK (derived from the float activations), cotangents slice-major like the forward tangents; the skip
         # connection is a separate accumulate (the kernel's residual input would be masked with the product).
-        split = TANGENT_PRECISION == "bf16x3" and _shape_ok_bf16x3(9, hid, W, True, H, hid) and hid % 64 == 0
+        split = cfg().tangent == "bf16x3" and _shape_ok_bf16x3(9, hid, W, True, H, hid) and hid % 64 == 0
         cd, csl = (hd, hsl) if split else (pn(hid), 16)    # layout of the hidden cotangents
         if train:
             t_in, hs, us = saved[0], saved[1::2], saved[2::2]  # h_0 .. h_K, u_0 .. u_{K-1}
@@ -1235,7 +1326,7 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
     hid, cout, H, W, HW = conv0.out_channels, convf.out_channels, geo.H, geo.W, geo.HW
     # hidden weight gradients on the split-precision kernel: it contracts column PAIRS of 16, so two sample groups are presented as
     # the two slices of one 32-column "sample" (slice stride = group stride) -- the batch is padded to a multiple of 32 then
-    pair = TANGENT_PRECISION == "bf16x3" and hid % 64 == 0
+    pair = cfg().tangent == "bf16x3" and hid % 64 == 0
     Bp = (B + 31) // 32 * 32 if pair else (B + 15) // 16 * 16
     G = Bp // 16
 

@@ -61,7 +61,7 @@ int cmf_pack_weight(const float* w, float* out, int cout, int cin, int taps, int
 
 /* Every stale pack of a model in ONE launch (a training step re-packs ~780 weights: round 3).  `table` is a DEVICE array of n
  * descriptors; entry k writes `total` elements of layout `kind` (0: cmf_pack_weight's floats, 1: cmf_pack_weight_bf16x3_t's bf16
- * halves) of the weight `w` to `out`, exactly as the single-weight entry points do.  For kind 1 with transpose != 0, cout / cin are
+ * halves, 2: cmf_pack_weight_f16x3's fp16 halves followed by its 16-byte trailer) of the weight `w` to `out`, exactly as the single-weight entry points do.  For kind 1 with transpose != 0, cout / cin are
  * the ADJOINT operator's (already swapped), as cmf_pack_weight_bf16x3_t expects them. */
 typedef struct {
   const float* w; void* out; long long total;
@@ -106,6 +106,12 @@ typedef struct {
                                                    stored values, [y > 0], in the CMF_F_RELU_BITS layout of the NEXT conv:
                                                    byte (sample*mask_np + px*(cout/8) + co/8), sample = np*nc + column
                                                    (primal pass: 16 samples in the column slots); NULL = off            */
+  const float* amax_in; float* amax_out;        /* cmf_conv_tangent_f16x3 only (else ignored).  amax_in: one device float >= the largest
+                                                   |x| the launch reads (NULL or 0: unknown -> no input scaling); the kernel multiplies x
+                                                   by the power of two that puts that maximum in [2^13, 2^14) before the fp16 split, so no
+                                                   input overflows fp16 and small ones keep their low half.  amax_out: one device float,
+                                                   atomically raised to max(y) over the stored values (the caller zeroes it: the next
+                                                   conv's amax_in, whose relu-on-load ignores negative values); NULL = off              */
 } cmf_conv_tangent_args;
 int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
 
@@ -123,6 +129,21 @@ int cmf_pack_weight_bf16x3(const float* w, void* out, int cout, int cin, long lo
  * [cout][cin][tap] = w[ci][co][8 - tap] (channels swapped, taps flipped: cmf_pack_weight's transpose for the split kernel) */
 int cmf_pack_weight_bf16x3_t(const float* w, void* out, int cout, int cin, int transpose, long long* out_bytes, void* stream);
 int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* a, void* stream);
+
+/* fp16 split-precision variant for the PRIMAL hidden convs of a ResNet coupler (networks.py:50-60 with 16 samples in the column
+ * slots): fmode CMF_F_SELF_RELU, taps == 9, cin % 32 == 0, cout % 64 == 0, tiles as cmf_conv_tangent_bf16x3, no output factor.
+ * Operands are split v = hi + lo with hi = fp16(v), lo = fp16(v - hi) (11 + 11 significant bits) and multiplied as
+ * hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation: ~2^-22 relative per product against bf16x3's 2^-16, so
+ * the relu masks taken from these activations flip as rarely as with exact fp32 products (profiles/r04_primal_precision_study.txt)
+ * at the bf16 MFMA rate.  fp16's narrow exponent is handled by exact power-of-two scales: the weights are packed times 2^k with
+ * max |w| 2^k in [2^11, 2^12) (cmf_pack_weight_f16x3: same layout as cmf_pack_weight_bf16x3_t plus a 16-byte trailer
+ * {2^k, 2^-k, 0, 0}; the max is taken on the device, no host synchronisation), the inputs times the power of two derived from
+ * amax_in; the epilogue undoes both (exact), the residual enters scaled.  mask_out IS supported (the sign bits of the stored
+ * values, as cmf_conv_tangent writes them).  `w` must come from cmf_pack_weight_f16x3.                                        */
+int cmf_pack_weight_f16x3(const float* w, void* out, int cout, int cin, int transpose, long long* out_bytes, void* stream);
+int cmf_conv_tangent_f16x3(const cmf_conv_tangent_args* a, void* stream);
+/* out[0] = max(out[0], max_i |x[i]|) over n floats (out is NOT cleared: the caller zeroes it or chains several tensors).   */
+int cmf_absmax(const float* x, long long n, float* out, void* stream);
 
 /* Weight gradient of the tangent convolution (training; the reference gets it from autograd through
  * get_conv2d_jvp / get_linear_jvp, jvp_layers.py:49-64, under loss.backward(), trainer.py:213):

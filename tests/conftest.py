@@ -116,3 +116,12 @@ def fp64_bound(fp64, ref32, pert=None, extra=None, rel=1e-4, k=3.0, abs_floor=No
 @pytest.fixture(scope="session")
 def golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "jitter_retry.npz")
+
+
+@pytest.fixture
+def kernel_scope():
+    """``kernel_scope(tangent=..., primal=...)``: run the rest of the test under that engine.KernelConfig (thread-local scope)."""
+    import contextlib
+    from cmf_amd import engine as E
+    with contextlib.ExitStack() as stack:
+        yield lambda **kw: stack.enter_context(E.scope(**kw))

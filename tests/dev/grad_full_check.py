@@ -21,7 +21,7 @@ KWS = {"full": dict(add_offdiagonal_metric_reg=True), "lik": dict(add_reconstruc
 y, lj = O.prehead(O.split_ops(ops)[0], x, torch.zeros_like(x))
 for setting in sys.argv[1:] or ["f32", "bf16x3"]:
     tp, wg = (setting.split("+") + ["same"])[:2]
-    E.TANGENT_PRECISION = tp
+    head.kernels = E.KernelConfig(tangent=tp, primal=head.kernels.primal)
     for kwname, kw in KWS.items():
         want_elbo = O.elbo(sd64, ops, x, noise=torch.zeros_like(x), **kw)["elbo"]
         want = dict(zip(keys, torch.autograd.grad(-want_elbo.mean(), [sd64[k] for k in keys], allow_unused=True)))

@@ -3,7 +3,7 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from cmf_amd import engine as E
-E.TANGENT_PRECISION = "bf16x3"
+E.scope(tangent="bf16x3").__enter__()
 B, C, H, W, nc = 3, 64, 14, 14, 64
 HW = H * W
 x = torch.randn(B, C, H, W, nc, device="cuda")

@@ -8,7 +8,7 @@ log-det / g_ij in float32 and float64), the hidden 3x3 primal convolutions emula
 
 Schemes (values / masks): a primal chain per arithmetic is carried side by side through every coupler network;
   f32/f32        the oracle as it is
-  bf16x3/bf16x3  three bf16 products (hi hi + hi lo + lo hi), what PRIMAL_PRECISION = "bf16x3" runs
+  bf16x3/bf16x3  three bf16 products (hi hi + hi lo + lo hi), what KernelConfig(primal="bf16x3") runs
   bf16x3/f32     split values, fp32 masks         f32/bf16x3   the reverse
   f16x3/f16x3    three fp16 products, lo = fp16(v - hi) UNscaled, weights pre-scaled per layer by 2^k (max |w| 2^k in [2^11, 2^12))
   f16x3u/f16x3u  the same without the weight scale (lo of a 0.04-sized weight is an fp16 subnormal)

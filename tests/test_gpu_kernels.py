@@ -19,11 +19,11 @@ def rel(a, b):
 @pytest.mark.parametrize("fmode", ["none", "relu", "tanh", "raw"])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("layout", ["panel", "slice"])
-def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, monkeypatch):
+def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, kernel_scope):
     """layout 'panel' = [sample][channel][pixel][nc]; 'slice' = the slice-major hidden layout
     [sample][pixel][16-column slice][channel][16] addressed through x_sl / y_sl (include/cmf_amd.h)."""
     from cmf_amd import engine as E
-    monkeypatch.setattr(E, "TANGENT_PRECISION", precision)
+    kernel_scope(tangent=precision)
     if precision == "bf16x3" and not E._use_bf16x3(taps, cin, W, False, H, cout):
         pytest.skip("shape not covered by the split-precision kernel (the engine falls back to fp32)")
     if layout == "slice" and (cin, cout, H) not in ((64, 64, 14), (64, 64, 28), (64, 64, 32), (2, 64, 14), (64, 4, 14), (16, 40, 5),
@@ -194,11 +194,11 @@ def test_gram_backward_matches_autograd(N, d, layout):
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("H,W", [(14, 14), (28, 28), (5, 14)])
-def test_conv_tangent_primal_in_column_slots(H, W, precision, monkeypatch):
+def test_conv_tangent_primal_in_column_slots(H, W, precision, kernel_scope):
     """16 samples in the 16 column slots: elementwise relu on load (SELF_RELU), bias, residual; and a tangent launch
     reading its relu' factor from that sample-grouped primal tensor (f_group = 16)."""
     from cmf_amd import engine as E
-    monkeypatch.setattr(E, "TANGENT_PRECISION", precision)
+    kernel_scope(tangent=precision)
     gen = torch.Generator().manual_seed(H * W)
     B, C, HW = 32, 64, H * W
     x = torch.randn(B, C, H, W, generator=gen)
@@ -226,11 +226,11 @@ def test_conv_tangent_primal_in_column_slots(H, W, precision, monkeypatch):
 
 
 @pytest.mark.parametrize("H,W", [(14, 14), (16, 16)])
-def test_relu_bit_masks_producer_and_consumer(H, W, monkeypatch):
+def test_relu_bit_masks_producer_and_consumer(H, W, kernel_scope):
     """The fp32 kernel's ``mask_out`` (sign bits of what it stores, one bit per sample / pixel / channel) and the split
     kernel's CMF_F_RELU_BITS factor mode: same tangent conv result as the float-activation RELU mode, bit for bit."""
     from cmf_amd import engine as E
-    monkeypatch.setattr(E, "TANGENT_PRECISION", "bf16x3")
+    kernel_scope(tangent="bf16x3")
     gen = torch.Generator().manual_seed(H)
     B, C, nc, HW = 32, 64, 32, H * W
     G = B // 16
@@ -326,12 +326,12 @@ def test_channel_sum(layout):
 
 @pytest.mark.parametrize("H,W,cl_out,cl_in", [(14, 14, 64, 64), (28, 28, 64, 64), (8, 16, 64, 128), (6, 14, 128, 64)])
 @pytest.mark.parametrize("layout", ["panel", "slice"])
-def test_transposed_conv_with_output_bit_mask_on_the_split_kernel(H, W, cl_out, cl_in, layout, monkeypatch):
+def test_transposed_conv_with_output_bit_mask_on_the_split_kernel(H, W, cl_out, cl_in, layout, kernel_scope):
     """Reverse-sweep conv on the split-precision kernel: transposed / tap-flipped bf16x3 pack, NO input factor, relu' of a
     float activation as an OUTPUT bit mask (cmf_relu_bits), then the skip connection through cmf_accumulate:
     y = skip + [act > 0] . conv^T(x)   against conv_transpose2d."""
     from cmf_amd import engine as E
-    monkeypatch.setattr(E, "TANGENT_PRECISION", "bf16x3")
+    kernel_scope(tangent="bf16x3")
     gen = torch.Generator().manual_seed(H * W + cl_in)
     B, nc, HW = 2, 32, H * W
     w = torch.randn(cl_out, cl_in, 3, 3, generator=gen) / (9 * cl_out) ** 0.5        # the LAYER's weight: cl_in -> cl_out

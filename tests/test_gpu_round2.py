@@ -558,13 +558,9 @@ def test_fused_mlp_coupler_is_what_the_golden_vectors_ran_on():
     """The reference-vector parity tests of the flat models must have gone through the fused kernel: timer names say so."""
     from cmf_amd import engine as E
     g, meta, cfg, dens = build("c2b_hepmass")
-    E.TIMER = E.KernelTimer(lambda name: True)
-    try:
-        with torch.no_grad():
-            out = dens.elbo(g["x"].cuda(), add_offdiagonal_metric_reg=True)
-        names = set(E.TIMER.by_name())
-    finally:
-        E.TIMER = None
+    with E.timing(lambda name: True) as timer, torch.no_grad():
+        out = dens.elbo(g["x"].cuda(), add_offdiagonal_metric_reg=True)
+    names = set(timer.by_name())
     assert rel(out["elbo"], g["elbo_0"]) < 1e-4
     assert "mlp_coupler_tangent" in names and "mlp_coupler_primal" in names
     assert not any(n.startswith("conv_tangent") for n in names)

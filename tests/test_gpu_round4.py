@@ -1,0 +1,209 @@
+"""Round-4 GPU tests: the fp16-split primal convolutions (cmf_conv_tangent_f16x3) -- values, relu' bit masks, the input-range
+chain, relu-mask flips against the float64 oracle -- and the per-head kernel configuration.  Every call goes through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, golden_model
+from test_gpu_parity import build, find_head, inner, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _unpack_bits(mask, C):
+    """BitMask.data (B, HW, C/8) uint8 -> bool (B, HW, C): bit j of byte o = channel 8 o + j."""
+    return ((mask.to(torch.int32).unsqueeze(-1) >> torch.arange(8, device=mask.device, dtype=torch.int32)) & 1).bool().flatten(2)
+
+
+@pytest.mark.parametrize("H,W", [(14, 14), (28, 28), (16, 16), (8, 32)])
+@pytest.mark.parametrize("scale", [1.0, 3e4, 1e-4])
+def test_f16x3_primal_conv_values_masks_and_range_chain(H, W, scale):
+    """One hidden primal conv with 16 samples in the column slots on the fp16-split kernel: relu on load, bias, residual against
+    float64 ``F.conv2d`` (fp32-grade: the split is 11 + 11 significant bits); the sign bits it writes for the next tangent conv;
+    the running maximum it hands to the next conv.  ``scale``: inputs far outside fp16's exponent range in either direction (the
+    power-of-two input scale derived from amax_in keeps them exact)."""
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(H * W)
+    B, C, HW = 32, 64, H * W
+    G = B // 16
+    x = scale * torch.randn(B, C, H, W, generator=gen)
+    w = torch.randn(C, C, 3, 3, generator=gen) / 24
+    bias = scale * torch.randn(C, generator=gen)
+    res = scale * torch.randn(B, C, H, W, generator=gen)
+    want = F.conv2d(torch.relu(x).double(), w.double(), bias.double(), padding=1) + res.double()
+    xg, rg = E.primal_regroup(x.cuda(), True), E.primal_regroup(res.cuda(), True)
+    wd = torch.nn.Parameter(w.cuda())
+    pn = (C * HW * 16, HW * 16, 16)
+    rng = torch.zeros(2, device="cuda")
+    E.absmax(xg, rng[0:1])
+    assert float(rng[0]) == float(x.abs().max())
+    outs = {}
+    for prec in ("f16x3", "f32"):
+        yg = torch.empty_like(xg)
+        m = E.BitMask(B, HW, C, "cuda")
+        m.data.fill_(0xAA)
+        kw = dict(amax_in=rng[0:1], amax_out=rng[1:2]) if prec == "f16x3" else {}
+        E.conv_tangent(xg, 0, *pn, wd, 9, yg, *pn, G, C, C, H, W, 16, fmode=E.F_SELF_RELU, bias=bias.cuda(), res_t=rg, precision=prec,
+                       mask_out=m.data, mask_np=m.np_bytes, **kw)
+        got = E.primal_regroup(yg.view(G, -1), False).view(B, C, H, W)
+        outs[prec] = (got, m)
+    got, m = outs["f16x3"]
+    e16, e32 = rel(got, want), rel(outs["f32"][0], want)
+    assert e16 < 4e-7 and e16 < 3 * e32 + 1e-7, (e16, e32)           # fp32-grade: within a small factor of the exact-fp32-product kernel
+    # the bit mask is the sign of what was stored, bit for bit
+    want_bits = (got > 0).permute(0, 2, 3, 1).reshape(B, HW, C)
+    assert torch.equal(_unpack_bits(m.data, C), want_bits)
+    # the running maximum covers every positive stored value (what the next conv's relu-on-load lets through)
+    assert float(rng[1]) == float(got.clamp_min(0).max())
+    # without a range word the kernel still works for inputs inside fp16's range
+    if scale == 1.0:
+        y2 = torch.empty_like(xg)
+        E.conv_tangent(xg, 0, *pn, wd, 9, y2, *pn, G, C, C, H, W, 16, fmode=E.F_SELF_RELU, bias=bias.cuda(), res_t=rg, precision="f16x3")
+        assert rel(E.primal_regroup(y2.view(G, -1), False).view(B, C, H, W), want) < 4e-7
+
+
+def test_f16x3_pack_single_and_batched_agree():
+    """cmf_pack_weight_f16x3 (two launches: scale, then pack) and kind 2 of cmf_pack_weights_batched write the same bytes, the
+    trailer holds the power of two that puts max |w| in [2^11, 2^12), forward and adjoint operator."""
+    import ctypes as C
+    from cmf_amd import engine as E, _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(5)
+    for cout, cin, tr, gain in ((64, 64, 0, 0.04), (64, 64, 1, 7.0), (128, 64, 0, 1e-3), (64, 32, 1, 300.0)):
+        w = (gain * torch.randn(cout, cin, 3, 3, generator=gen)).cuda()
+        pc, pi = (cin, cout) if tr else (cout, cin)                    # the packed operator's channels
+        n = C.c_longlong(0)
+        _lib.check(lib.cmf_pack_weight_f16x3(None, None, pc, pi, tr, C.byref(n), None), "size")
+        one, two = torch.zeros(n.value, dtype=torch.uint8, device="cuda"), torch.ones(n.value, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.cmf_pack_weight_f16x3(E._p(w), E._p(one), pc, pi, tr, None, E._stream()), "pack")
+        desc = np.zeros(1, dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("total", "<i8"), ("cout", "<i4"), ("cin", "<i4"), ("taps", "<i4"),
+                                           ("transpose", "<i4"), ("kind", "<i4"), ("reserved", "<i4")]))
+        desc[0] = (w.data_ptr(), two.data_ptr(), (n.value - 16) // 2, pc, pi, 9, tr, 2, 0)
+        table = torch.from_numpy(desc.view(np.uint8).copy()).cuda()
+        _lib.check(lib.cmf_pack_weights_batched(E._p(table), 1, E._stream()), "batched")
+        assert torch.equal(one, two)
+        trailer = one[-16:].view(torch.float32).cpu()
+        k = float(torch.log2(trailer[0]))
+        assert k == round(k) and float(trailer[0] * trailer[1]) == 1.0 and 2 ** 11 <= float(w.abs().max()) * 2 ** k < 2 ** 12
+        halves = one[:-16].view(torch.float16).float()
+        assert bool(torch.isfinite(halves).all()) and float(halves.abs().max()) < 2 ** 12
+
+
+def _oracle_hidden_chain(sd, op, x):
+    """float64 pre-activations of every hidden layer of a ResNet coupler (oracle.net_forward's chain, networks.py:50-60)."""
+    from oracle import cmf_oracle as O
+    p = O._net_keys(op)
+    n = len(op["hidden"])
+    d = lambda k: sd[k].double()
+    h = F.conv2d(x.double(), d(p + "module.0.weight"), None, padding=1)
+    acts = [h]
+    for i in range(1, n + 1):
+        o = F.conv2d(torch.relu(h), d(f"{p}module.{i}.conv1.weight"), d(f"{p}module.{i}.conv1.bias"), padding=1)
+        h = F.conv2d(torch.relu(o), d(f"{p}module.{i}.conv2.weight"), d(f"{p}module.{i}.conv2.bias"), padding=1) + h
+        acts += [o, h]
+    return acts
+
+
+def test_relu_mask_flips_of_the_f16x3_primal_against_the_float64_oracle():
+    """the relu masks the tangent pass takes from the primal activations.  Full-size MNIST model, the first 16
+    inputs of ``c3_mnist_stats32`` decoded layer by layer by the ORACLE (float64); at every coupling layer the HIP primal pass runs
+    on the oracle's layer input in both arithmetics and its bit masks are compared with the signs of the oracle's float64
+    activations.  The fp16-split primal may flip at most 1.5 x the masks the exact-fp32-product primal flips (+ 3 sigma of a
+    Poisson count: the counts are a dozen out of 10^8), and a small multiple of the flips the float32 oracle itself shows."""
+    import cmf_amd
+    from cmf_amd import engine as E
+    from cmf_amd.bijections import AffineCouplingBijection
+    from cmf_amd.recipe import fill_state_dict
+    from oracle import cmf_oracle as O
+    g, meta = load_golden("c3_mnist_stats32")
+    _, _, _, ops, sd = golden_model(meta)
+    cfg = cmf_amd.get_config("mnist", **meta["overrides"])
+    dens = cmf_amd.get_density(cmf_amd.get_schema(cfg), torch.zeros(4, 1, 28, 28))
+    dens.load_state_dict(fill_state_dict(dens.state_dict(), seed=meta["recipe_seed"]), strict=True)
+    dens = dens.cuda().eval()
+    prog = find_head(dens).program
+    pre, head, flow_ops, base, prior_ops = O.split_ops(ops)
+    n = 16
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    z = O.tail_scatter(sd64, base, g["z_low"][:n].double())
+    layers = [m for m in prog.layers]
+    assert len(layers) == len(flow_ops)
+    flips, total, flips32cpu = {"f16x3": 0, "f32": 0}, 0, 0
+    for m, op in zip(reversed(layers), reversed(flow_ops)):
+        k = op["kind"]
+        if k == "acl":
+            assert isinstance(m, AffineCouplingBijection)
+            # the network input as the oracle's ACL forms it (mask . z for the checkerboard layers, the pass-through channels else)
+            view = m.view("cuda")
+            zf = z.float().cuda()
+            xin = sd64[op["prefix"] + "mask"] * z if op["mask_type"] == "checkerboard" else O._cw_split(op, z)[0]
+            acts64 = _oracle_hidden_chain(sd64, op, xin)
+            acts32 = _oracle_hidden_chain(sd, op, xin.float())       # the float32 oracle (ATen CPU convs) on the same input
+            want = [(a > 0) for a in acts64[1:-1]]                    # the activations whose masks the tangent pass reads as bits
+            flips32cpu += sum(int(((a32 > 0) != w).sum()) for a32, w in zip(acts32[1:-1], want))
+            for prec in ("f16x3", "f32"):
+                with E.scope(primal=prec):
+                    y, gg, acts = E.net_primal(m.net, zf, view, need_acts="bits")
+                masks = [a for a in acts if isinstance(a, E.BitMask)]
+                assert len(masks) == len(want)
+                for bm, w in zip(masks, want):
+                    got = _unpack_bits(bm.data, w.shape[1]).reshape(n, view.geom.H, view.geom.W, -1).permute(0, 3, 1, 2).cpu()
+                    flips[prec] += int((got != w).sum())
+            total += sum(w.numel() for w in want)
+            z = O.acl_z_to_x(sd64, op, z)
+        elif k == "flatten":
+            z = z.reshape(z.shape[0], *op["x_shape"])
+        elif k == "squeeze":
+            z = O.squeeze_z_to_x(z, op["factor"])
+        elif k == "split":
+            z = torch.cat((z, torch.zeros_like(z)), 1)
+    print(f"relu-mask flips vs the float64 oracle over {total:.2e} mask bits: f16x3 primal {flips['f16x3']}, fp32-MFMA primal {flips['f32']}, "
+          f"float32 CPU oracle {flips32cpu}")
+    assert flips["f16x3"] <= 1.5 * flips["f32"] + 3 * max(flips["f32"], 1) ** 0.5 + 2
+    assert flips["f16x3"] <= 3 * max(flips32cpu, 4)
+
+
+def test_kernel_config_is_per_head_and_thread_local():
+    """VERDICT r3 item 8 / SURVEY 8b: the kernels' arithmetic is an attribute of the head (``head.kernels``), carried by a
+    thread-local scope.  Two threads evaluating two heads with different configurations at the same time get the results of the
+    sequential runs bit for bit; nothing is process-global."""
+    import copy
+    import threading
+    from cmf_amd import engine as E
+    g, meta, cfg, dens_a = build("mini_mnist")
+    dens_b = copy.deepcopy(dens_a)
+    ha, hb = find_head(dens_a), find_head(dens_b)
+    ha.kernels = E.KernelConfig(tangent="bf16x3", primal="f16x3")
+    hb.kernels = E.KernelConfig(tangent="f32", primal="f32")
+    assert E.cfg().tangent == "bf16x3" and E.cfg().primal == "f16x3"           # the defaults, untouched by the heads
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.randint(0, 256, (32, 1, 28, 28), generator=gen).float() + torch.rand(32, 1, 28, 28, generator=gen)).cuda()
+    kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=True)
+
+    def run(d):
+        with torch.no_grad():
+            return inner(d, True).elbo(x.clone(), **kw)["elbo"].clone()
+
+    want = [run(dens_a), run(dens_b)]
+    torch.cuda.synchronize()
+    got, errs, seen = [None, None], [], [None, None]
+
+    def worker(i, d):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    got[i] = run(d)
+                seen[i] = repr(E.cfg())                                           # outside a head's scope: the defaults
+            s.synchronize()
+        except Exception as e:                                                    # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i, d)) for i, d in enumerate((dens_a, dens_b))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert rel(want[0], want[1]) < 1e-5 and not torch.equal(want[0], want[1])    # two arithmetics, the same density
+    assert seen[0] == seen[1] == repr(E.KernelConfig())

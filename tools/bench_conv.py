@@ -18,7 +18,7 @@ from cmf_amd import _lib
 if args.lib:
     _lib.LIB_PATH = os.path.abspath(args.lib)
 from cmf_amd import engine as E
-E.TANGENT_PRECISION = args.precision
+E.scope(tangent=args.precision).__enter__()               # for the whole process
 B, H, nc, ch = args.B, args.hw, args.nc, 64
 HW = H * H
 torch.manual_seed(0)

@@ -34,14 +34,15 @@ for _ in range(args.warmup):
     step()
 torch.cuda.synchronize()
 torch.cuda.reset_peak_memory_stats()
-E.TIMER = E.KernelTimer(lambda name: True)
+_timing = E.timing(lambda name: True)
+_timer = _timing.__enter__()
 t0 = time.perf_counter()
 for _ in range(args.steps):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
-by = E.TIMER.by_name() if hasattr(E.TIMER, "by_name") else {}
-E.TIMER = None
+by = _timer.by_name()
+_timing.__exit__(None, None, None)
 print(f"train step B={args.batch}: {1e3*dt:.1f} ms  ({args.batch/dt:.1f} samples/s, {1/dt:.3f} steps/s)  loss {float(loss.detach()):.1f}  "
       f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 rows = [kv for kv in sorted(by.items(), key=lambda kv: -kv[1][1]) if kv[1][1] / args.steps >= 0.2] if by else []

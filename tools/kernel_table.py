@@ -16,10 +16,9 @@ x = synth_batch(dataset, shape, B, 0, "cuda")
 kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=off, likelihood_wt=1., metric_wt=1.)
 with torch.no_grad():
     inner.elbo(x.clone(), **kw)
-    E.TIMER = E.KernelTimer(lambda name: True)
-    inner.elbo(x.clone(), **kw)
-    rows = E.TIMER.by_name()
-    E.TIMER = None
+    with E.timing(lambda name: True) as timer:
+        inner.elbo(x.clone(), **kw)
+    rows = timer.by_name()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); inner.elbo(x.clone(), **kw); e1.record(); torch.cuda.synchronize()
