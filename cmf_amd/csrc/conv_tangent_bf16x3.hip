@@ -923,6 +923,14 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     cur_mrs = nxt_mrs;
   }
   if constexpr (F16) {
+    // The last item's "next residual" loads (zero-record descriptor) are still landing in the accumulator registers: drain them
+    // and keep those registers allocated until then -- hipcc believes the inline-asm loads completed where they were issued, and
+    // reused the dead accumulators for the reduction below (the maximum came out too small, differently from run to run).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < PW; ++p)
+#pragma unroll
+      for (int c = 0; c < CW; ++c) asm volatile("" ::"v"(acc[p][c]));
     if (a.amax_out) {                                              // values >= 0 order like their bit patterns
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) ymax = __builtin_fmaxf(ymax, __shfl_xor(ymax, o, 64));

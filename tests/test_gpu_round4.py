@@ -50,7 +50,9 @@ def test_f16x3_primal_conv_values_masks_and_range_chain(H, W, scale):
         outs[prec] = (got, m)
     got, m = outs["f16x3"]
     e16, e32 = rel(got, want), rel(outs["f32"][0], want)
-    assert e16 < 4e-7 and e16 < 3 * e32 + 1e-7, (e16, e32)           # fp32-grade: within a small factor of the exact-fp32-product kernel
+    # fp32-grade: within a small factor of the exact-fp32-product kernel (whose residual is added once, after the products; here it
+    # is the accumulators' initial value, so every partial sum is rounded at the residual's magnitude -- like the bf16 split kernel)
+    assert e16 < 1e-6 and e16 < 3 * e32 + 1e-7, (e16, e32)
     # the bit mask is the sign of what was stored, bit for bit
     want_bits = (got > 0).permute(0, 2, 3, 1).reshape(B, HW, C)
     assert torch.equal(_unpack_bits(m.data, C), want_bits)
@@ -60,7 +62,7 @@ def test_f16x3_primal_conv_values_masks_and_range_chain(H, W, scale):
     if scale == 1.0:
         y2 = torch.empty_like(xg)
         E.conv_tangent(xg, 0, *pn, wd, 9, y2, *pn, G, C, C, H, W, 16, fmode=E.F_SELF_RELU, bias=bias.cuda(), res_t=rg, precision="f16x3")
-        assert rel(E.primal_regroup(y2.view(G, -1), False).view(B, C, H, W), want) < 4e-7
+        assert rel(E.primal_regroup(y2.view(G, -1), False).view(B, C, H, W), want) < 1e-6
 
 
 def test_f16x3_pack_single_and_batched_agree():
@@ -171,7 +173,12 @@ def test_kernel_config_is_per_head_and_thread_local():
     import copy
     import threading
     from cmf_amd import engine as E
-    g, meta, cfg, dens_a = build("mini_mnist")
+    import cmf_amd
+    from cmf_amd.recipe import fill_state_dict
+    cfg = cmf_amd.get_config("mnist", latent_dimension=16, g_hidden_channels=[64], log_jacobian_method="cholesky")   # 64 hidden channels:
+    dens_a = cmf_amd.get_density(cmf_amd.get_schema(cfg), torch.zeros(1, 1, 28, 28))                               # the split kernels run
+    dens_a.load_state_dict(fill_state_dict(dens_a.state_dict(), seed=3), strict=True)
+    dens_a = dens_a.cuda().eval()
     dens_b = copy.deepcopy(dens_a)
     ha, hb = find_head(dens_a), find_head(dens_b)
     ha.kernels = E.KernelConfig(tangent="bf16x3", primal="f16x3")
