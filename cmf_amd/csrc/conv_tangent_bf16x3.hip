@@ -125,10 +125,16 @@ __device__ __forceinline__ int xslot(int col, int pix) { return (((col & 3) << 2
 // packed times 2^k, inputs times the power of two derived from *amax_in; the epilogue multiplies by the inverse, a residual is
 // scaled when it lands), the sign bits of the stored values written as the next conv's relu' bit mask (mask_out) and max(y) raised
 // into *amax_out.  SELF mode only.
-template <int COT, int PXW, int MODE, bool F16 = false>
+// FRES (F16 launches with a residual): the residual is NOT the accumulators' initial value -- every partial sum would be rounded
+// at the residual's magnitude, 54 times per output, which cost the primal chain 2-3x the error of the exact-fp32-product kernel
+// (measured: median g_ij error of the full-size model 1.3e-6 against 4e-7).  The accumulators start at zero, the item's last chunk
+// carries no tail, and after it the wave loads the residual into the registers its fragments occupied and adds it ONCE, after the
+// products, like cmf_conv_tangent does.  The round trip is exposed once per item: ~15 % on the 80 launches of a step that have one.
+template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false>
 __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
                                                                        int nslices, int ncog, int total) {
   static_assert(!F16 || (MODE == 2 && COT == 4), "the fp16 variant is the primal pass: SELF mode, 64-channel groups");
+  static_assert(!FRES || F16, "residual-in-the-epilogue is the fp16 variant's");
   // MODE: 0 = general factor formula, 1 = relu factor (2 instead of 6 VALU per channel in the loader), 2 = SELF (the
   // input's own relu, no factor stream).  Compile-time: every loader VALU instruction delays the MFMA wave it shares
   // a SIMD with.
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       }
     }
   };
-  auto store_pixel = [&](const Item& it, int p) __attribute__((always_inline)) {
+  auto store_pixel = [&](const Item& it, int p, f32x4 radd0, f32x4 radd1) __attribute__((always_inline)) {
     [[maybe_unused]] unsigned mbits = 0;
     [[maybe_unused]] f32x4 vst[CW];
 #pragma unroll
@@ -703,6 +709,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       }
       if constexpr (F16) v = v * oscale + bias[c];                 // undo the operand scales (exact), then the bias
       else v += bias[c];                                           // per-channel constant (primal bias)
+      if constexpr (FRES) v += c == 0 ? radd0 : radd1;             // the residual, once, after the products
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, v), cur_yrs, vo,
                                              it.ypix + 4 * (((p / C::TW) * a.W + p % C::TW) * y_px + c * 16 * y_co), 0);
       if constexpr (F16) {
@@ -764,7 +771,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     if (LAST) {                                    // timing-only build: the MFMA waves only run the tail and the barriers
 #pragma unroll
       for (int p = 0; p < PW; ++p) {
-        store_pixel(cur, p);
+        store_pixel(cur, p, f32x4{}, f32x4{});
         init_pixel(nxt, nxt_rrs, p);
       }
     }
@@ -842,7 +849,11 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         }
       }
 #endif
-      if (FIRST && s == 0) {
+      if (FIRST && s == 0 && FRES) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (FIRST && s == 0 && !FRES) {
         wait_res(p, false);
         if constexpr (F16) {                                       // the accumulators hold (2^k xscale) x the result
 #pragma unroll
@@ -865,8 +876,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
           acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
         }
       }
-      if (LAST && s == KS - 1) {
-        store_pixel(cur, p);
+      if (LAST && s == KS - 1 && !FRES) {
+        store_pixel(cur, p, f32x4{}, f32x4{});
         init_pixel(nxt, nxt_rrs, p);
       }
       // keep this step's reads-then-MFMAs(-then-tail) order: without the fence hipcc's scheduler re-clusters the
@@ -876,8 +887,10 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   };
 
   int g = 0;                                                       // stream chunk index -> LDS stage g & 1
+  if constexpr (!FRES) {
 #pragma unroll
-  for (int p = 0; p < PW; ++p) init_pixel(cur, nxt_rrs, p);
+    for (int p = 0; p < PW; ++p) init_pixel(cur, nxt_rrs, p);
+  }
   // item 0: a block of loads, not the tail pattern (+ the bias)
   static_assert(CW == 2 || CW == 1, "operand list below");
   if constexpr (CW == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1])::"memory");
@@ -918,6 +931,36 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     }
     next_context();
     step(F{}, T{}, T{}, std::integral_constant<int, 0>{});
+    if constexpr (FRES) {
+      // epilogue with the residual: groups of GP pixels -- their residual tiles land in the registers the chunk's fragments just
+      // freed (hipcc counts these waits itself: plain builtin loads, nothing else in flight), then scale + bias + residual,
+      // stores, sign bits, running maximum per pixel
+      constexpr int GP = PW > 14 ? PW / 4 : PW / 2;               // 16-pixel waves hold 128 accumulators: smaller groups
+      int np, slice, cog;
+      {
+        int tile;
+        decode(item, tile, slice, cog, np);
+      }
+      const unsigned long long ru = reinterpret_cast<unsigned long long>(a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) +
+                                                                         (long long)cog * 64 * r_co);
+      const auto rrs = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ru >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ru)), 0, 0x7fffff00, RS_FLAGS);
+#pragma unroll
+      for (int p0 = 0; p0 < PW; p0 += GP) {
+        f32x4 rb[GP][CW];
+#pragma unroll
+        for (int q = 0; q < GP; ++q)
+#pragma unroll
+          for (int c = 0; c < CW; ++c) {
+            const int p = p0 + q;
+            rb[q][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rrs, rvoff, cur.rpix + 4 * (((p / C::TW) * a.W + p % C::TW) * r_px + c * 16 * r_co), 0));
+          }
+#pragma unroll
+        for (int q = 0; q < GP; ++q) store_pixel(cur, p0 + q, rb[q][0], rb[q][CW - 1]);
+      }
+    }
     cur = nxt;
     cur_yrs = nxt_yrs;
     cur_mrs = nxt_mrs;
@@ -999,14 +1042,14 @@ __global__ __launch_bounds__(1024) void pack_f16_scale_kernel(const float* __res
   }
 }
 
-template <int COT, int PXW, int MODE, bool F16 = false>
+template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false>
 int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   using C = BCfg<COT, PXW>;
   const int tiles_x = cmf_ceil_div(a.W, C::TW), tiles = tiles_x * cmf_ceil_div(a.H, C::TH);
   const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
-  auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE, F16>;
+  auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE, F16, FRES>;
   constexpr int lds = C::LDS_BYTES;
   if (hipError_t e = cmf_set_dynamic_lds((const void*)k, lds); e != hipSuccess) return (int)e;   // per device (runtime.hip)
   const int n_cu = cmf_device_cus();
@@ -1132,5 +1175,6 @@ extern "C" int cmf_conv_tangent_f16x3(const cmf_conv_tangent_args* ap, void* str
   if (!(t14 || t8)) return CMF_EINVAL;
   if (a.bias && a.cout > 64) return CMF_EINVAL;                 // the per-channel constants are fetched once per launch
   hipStream_t s = (hipStream_t)stream;
+  if (a.r) return t14 ? launch<4, 7, 2, true, true>(a, s) : launch<4, 4, 2, true, true>(a, s);
   return t14 ? launch<4, 7, 2, true>(a, s) : launch<4, 4, 2, true>(a, s);
 }
