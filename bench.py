@@ -86,7 +86,10 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (never a measurement)")
     ap.add_argument("--no-legs", action="store_true", help="default C3 run only: skip the secondary measurements (N = 1: c5, c2b, "
                                                             "c5_train, train; N > 1: strong_c3, c5)")
-    ap.add_argument("--leg-steps", type=int, default=3, help="timed steps of each secondary measurement")
+    ap.add_argument("--leg-steps", type=int, default=10, help="timed steps of each secondary measurement")
+    ap.add_argument("--force-group", action="store_true",
+                    help="N = 1: build a ONE-rank process group anyway and route the timing through its collectives (barrier, "
+                         "(sum, count) all-reduce, MAX of the times) -- RCCL itself on a one-GPU box (tests/test_gpu_round4.py)")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="--gpus N from a bare shell: seconds before the parent "
                                                                           "stops every rank and returns 124")
     ap.add_argument("--train", action="store_true",
@@ -118,11 +121,13 @@ def spawn_ranks(args, argv, script=None):
     they would otherwise sit in the rendezvous or a collective until the backend's own timeout -- and an overall deadline
     (--launch-timeout) bounds the whole run.  Nothing is ever re-executed in a process that has touched the GPU."""
     import threading
+    attempt = getattr(args, "_launch_attempt", 0)
+    t_start = time.monotonic()
     with socket.socket() as s:
         s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]                      # released just before the ranks start; a clash shows up as a failed rank
-    procs = []
+        port = s.getsockname()[1]                      # released just before the ranks start: another process may grab it in
+    procs = []                                         # between -- rank 0 then fails the rendezvous (exit 3) and we retry ONCE
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -160,6 +165,13 @@ def spawn_ranks(args, argv, script=None):
     if timed_out:
         print(f"[bench] ranks still running after --launch-timeout {args.launch_timeout:.0f} s: stopped (codes {codes})", file=sys.stderr)
         return 124
+    if 3 in codes and attempt == 0 and time.monotonic() - t_start < 90 and not any(l.lstrip().startswith("{") for l in lines):
+        # exit code 3 = init_group could not build the process group (run_rank): within the first seconds that is the rendezvous
+        # -- most likely the port was taken between the probe and rank 0's bind.  Fresh children on a fresh port, once.
+        print(f"[bench] process group failed within {time.monotonic() - t_start:.0f} s (codes {codes}): retrying once on a new port",
+              file=sys.stderr)
+        args._launch_attempt = 1
+        return spawn_ranks(args, argv, script)
     if any(codes):
         print(f"[bench] rank exit codes {codes} (a failing rank stops the others; its own message is above)", file=sys.stderr)
         return next(c for c in codes if c and c > 0) if any(c and c > 0 for c in codes) else 1
@@ -226,9 +238,61 @@ def cpu_baseline(schema, shape, sd, B_cpu, dataset, off, label):
         t0 = time.perf_counter()
         O.elbo(sd, ops, x, add_offdiagonal_metric_reg=off, noise=noise, flavour="ref_equivalent")
         dt = time.perf_counter() - t0
-    return {"value": B_cpu / dt, "unit": "evals/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": B_cpu / dt, "unit": "evals/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
             "sample": f"B={B_cpu}, {label}, one elbo call, {dt:.1f} s, "
                       f"oracle.jtj_ref_equivalent (column loop + primal recompute = what the reference executes)"}
+
+
+def cpu_model():
+    """'model name' of /proc/cpuinfo ("state core count and CPU model")."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+#: libcmf_amd symbol -> stage of the per-stage breakdown (calls inside FlowProgram.encode all count as "encode")
+STAGE_OF = {"cmf_conv_tangent_bf16x3": "tangent_hidden", "cmf_conv_tangent": "tangent_first_last",
+            "cmf_conv_tangent_f16x3": "primal", "cmf_conv_primal": "primal", "cmf_primal_regroup": "primal", "cmf_absmax": "primal",
+            "cmf_acl_tangent": "acl", "cmf_acl_primal": "acl", "cmf_gram_cholesky": "gram_cholesky", "cmf_cholesky_retry": "gram_cholesky",
+            "cmf_mlp_coupler": "mlp_coupler"}
+STAGES = ("encode", "primal", "tangent_hidden", "tangent_first_last", "acl", "gram_cholesky", "other", "host_gap")
+
+
+def stages_leg(wl, ms_per_step, steps=2):
+    """SURVEY 8d "per-stage times (encode, decode + tangents, Gram, Cholesky, reductions)": ``steps`` eager evaluations AFTER the timed
+    region with EVERY libcmf_amd launch bracketed by HIP events (cmf_amd._lib.trace), folded into stages by symbol and by the
+    FlowProgram phase the call was made in.  ms / step; ``host_gap`` = the timed region's ms_per_step minus the kernels' sum (launch
+    gaps, torch's own fill / copy kernels, the event overhead's mirror image), so the stages sum to ms_per_step."""
+    import torch
+    from cmf_amd import _lib
+    with torch.no_grad():
+        wl.inner.elbo(wl.x, **wl.kw)
+        torch.cuda.synchronize()
+        with _lib.trace() as rec:
+            for _ in range(steps):
+                wl.inner.elbo(wl.x, **wl.kw)
+            torch.cuda.synchronize()
+    out = {k: 0.0 for k in STAGES}
+    launches = {k: 0 for k in STAGES}
+    for name, ph, e0, e1 in rec:
+        st = "encode" if ph in ("encode", "encode_nested") else STAGE_OF.get(name, "other")
+        if st == "mlp_coupler":
+            st = "tangent_hidden"                          # flat models: the fused coupler kernel IS the tangent pass
+        out[st] += e0.elapsed_time(e1) / steps
+        launches[st] += 1
+    kernels = sum(out.values())
+    out["host_gap"] = ms_per_step - kernels
+    return {"unit": "ms/step", **{k: round(v, 4) for k, v in out.items()}, "kernels_sum": round(kernels, 4),
+            "launches_per_step": {k: v // steps for k, v in launches.items() if v},
+            "note": f"HIP events around every libcmf_amd launch of {steps} eager steps after the timed region; primal = the coupler "
+                    "networks' primal pass of the decode side (first conv, regroup, hidden convs, 1x1 + ScaledTanh), encode = the "
+                    "whole encode pass; host_gap = ms_per_step - kernels_sum"}
 
 
 def pmc_traffic(precision, B):
@@ -374,7 +438,7 @@ class Workload:
         self.kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=self.off, likelihood_wt=1., metric_wt=1.)
 
 
-def eval_timed(wl, world, steps, warmup, timer_select=None, graph=None):
+def eval_timed(wl, world, steps, warmup, timer_select=None, graph=None, grouped=None):
     """W untimed + K timed ``elbo`` steps bracketed by barrier + synchronize; returns (max-over-ranks seconds, last loss,
     per-kernel HIP-event rows or None, world size the process group reported)."""
     import torch
@@ -386,8 +450,10 @@ def eval_timed(wl, world, steps, warmup, timer_select=None, graph=None):
         out = graph(wl.x) if graph is not None else wl.inner.elbo(wl.x, **wl.kw)
         return allreduce_mean_elbo(out["elbo"])          # (sum, count) all-reduce; plain mean on one rank
 
+    grouped = world > 1 if grouped is None else grouped
+
     def fence():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -405,7 +471,7 @@ def eval_timed(wl, world, steps, warmup, timer_select=None, graph=None):
     rows = timer.by_name() if timer is not None else None
     tmax = torch.tensor([dt], device=wl.device, dtype=torch.float64)
     seen = 1
-    if world > 1:
+    if grouped:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         seen = dist.get_world_size()
     return float(tmax.item()), loss, rows, seen
@@ -488,8 +554,15 @@ def run_rank(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device("cuda", 0 if args.share_gpu else local)
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 or args.force_group:
+        if "MASTER_ADDR" not in os.environ:                  # --force-group from a bare shell
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                free = s_.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         init_group(args, world, device)
+    grouped = world > 1 or args.force_group
 
     B = args.batch // world if args.strong else args.batch
     wl = Workload(args.config, B, rank, device, args.precision, args.primal_precision)
@@ -503,20 +576,27 @@ def run_rank(args):
         line = train_leg(args.steps, args.warmup, args.config, inner, x, B, rank, world, device, off)
         if rank == 0:
             print(json.dumps(line), flush=True)
-        if world > 1:
+        if grouped:
             dist.destroy_process_group()
         return
 
     graph, graph_note = None, None
     if args.graph:
         graph, graph_note = capture_graph(wl)
+        if grouped:
+            # a capture that fails on ONE rank must not send the ranks down different paths (different numbers of
+            # collectives -> a stall until the watchdog): everybody replays, or nobody does
+            ok = torch.tensor([1.0 if graph is not None else 0.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0 and graph is not None:
+                graph, graph_note = None, "HIP-graph capture failed on another rank: every rank times eager launches"
         args.graph = graph is not None
 
     # the headline keeps its round-1 definition: only the dominant kernel family carries events inside the timed region
     select = None
     if not args.no_kernel_timer and graph is None:
         select = (lambda name: name == HIDDEN_CONV) if args.config in ("c3", "c5") else (lambda name: True)
-    dt, loss, rows, seen = eval_timed(wl, world, args.steps, args.warmup, select, graph)
+    dt, loss, rows, seen = eval_timed(wl, world, args.steps, args.warmup, select, graph, grouped)
     if graph is not None and not args.no_kernel_timer:       # replayed graphs cannot carry events: eager steps, outside the timed region
         _, _, rows, _ = eval_timed(wl, world, 3, 1, lambda name: True, None)
 
@@ -529,6 +609,9 @@ def run_rank(args):
         legs["strong_c3"] = eval_leg("c3", max(1, 512 // world), rank, world, device, args.leg_steps, 1, args.precision, "strong",
                                      graph=args.graph, primal=args.primal_precision)
         legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph, primal=args.primal_precision)
+    stages = None
+    if rank == 0 and not args.train and not args.no_kernel_timer and not args.hutchinson:
+        stages = stages_leg(wl, 1e3 * dt / args.steps)
     f32 = None
     if default_run and world == 1:
         if not args.no_f32_exact:
@@ -573,6 +656,10 @@ def run_rank(args):
             line["roofline"] = roofline_of(name, n, ms, fl, by, step_ms, args.precision, B, pmc=(args.config == "c3"))
             if args.graph:
                 line["roofline"]["note"] = "kernel events from 3 eager steps after the timed graph replays; share_of_step = share of GPU kernel time"
+        if stages is not None:
+            line["stages"] = stages
+        if args.force_group:
+            line["config"]["process_group"] = f"{args.backend}, {seen} rank(s), forced"
         if graph_note:
             line["config"]["graph_capture_failed"] = graph_note
         if f32 is not None:
@@ -583,7 +670,7 @@ def run_rank(args):
         if world == 1 and args.cpu_batch > 0:
             line["cpu_baseline"] = cpu_baseline(schema, shape, {k: v.cpu() for k, v in sd.items()}, args.cpu_batch, dataset, off, label)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -4,6 +4,7 @@ The product path has no CPU fallback: if the HIP library is missing, loading fai
 """
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcmf_amd.so")
@@ -112,13 +113,66 @@ SIGNATURES = {
 }
 
 _lib = None
+_tls = threading.local()
+
+
+class _Traced:
+    """``load()``'s return value while a ``trace()`` is active on the calling thread: every foreign call is bracketed by two HIP
+    events on the current stream and recorded as (symbol, phase label, event, event).  bench.py's per-stage breakdown."""
+
+    def __init__(self, lib, sink):
+        self._lib, self._sink = lib, sink
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("cmf_"):
+            return fn
+        import torch
+
+        def call(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            self._sink.append((name, getattr(_tls, "phase", None), e0, e1))
+            return rc
+        return call
+
+
+class trace:
+    """``with trace() as records:`` -- every libcmf_amd call of THIS thread inside the block is timed with HIP events (a
+    diagnostic mode: two event records per launch cost a few microseconds each); ``phase(label)`` tags the calls."""
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "sink", None)
+        _tls.sink = []
+        return _tls.sink
+
+    def __exit__(self, *exc):
+        _tls.sink = self.prev
+        return False
+
+
+class phase:
+    def __init__(self, label):
+        self.label = label
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "phase", None)
+        if self.prev is None:                               # the outermost label wins (encode_train calls encode's helpers)
+            _tls.phase = self.label
+
+    def __exit__(self, *exc):
+        _tls.phase = self.prev
+        return False
 
 
 def load():
     """Load libcmf_amd.so and bind every declared symbol; raises if the library or a symbol is missing."""
     global _lib
+    sink = getattr(_tls, "sink", None)
     if _lib is not None:
-        return _lib
+        return _lib if sink is None else _Traced(_lib, sink)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP kernels are the only implementation of this path "

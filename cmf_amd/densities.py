@@ -274,7 +274,7 @@ def _scoped(fn):
 
     @functools.wraps(fn)
     def run(self, *args, **kwargs):
-        with E.scope(self.head.kernels):
+        with E.scope(self.head.kernels), E._lib.phase(fn.__name__):
             return fn(self, *args, **kwargs)
     return run
 

@@ -14,7 +14,8 @@ __all__ = ["shard_batch", "broadcast_state", "allreduce_mean_elbo", "allreduce_g
 
 
 def _active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """A process group exists -- of any size: a one-rank RCCL group still runs its collectives (bench.py --force-group)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_batch(x, rank=None, world=None):

@@ -379,7 +379,15 @@ def test_bench_contract_line():
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["value"] > 0
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and isinstance(c.get("cpu_model"), str) and c["cpu_model"]
+    # round 4 (SURVEY 8d "per-stage times"): stages in ms / step that sum to ms_per_step (host_gap is the remainder)
+    st = d["stages"]
+    names = ("encode", "primal", "tangent_hidden", "tangent_first_last", "acl", "gram_cholesky", "other", "host_gap")
+    for k in names:
+        assert k in st, k
+    assert abs(sum(st[k] for k in names) - d["ms_per_step"]) <= 0.03 * d["ms_per_step"]
+    assert all(st[k] > 0 for k in names[:-2]) and st["tangent_hidden"] > st["primal"] > 0
+    assert abs(st["kernels_sum"] - sum(st[k] for k in names[:-1])) < 1e-2
     # round 3: the secondary measurements of SURVEY 8d ride in the default line, on the driver's clock
     for leg, unit, per_gpu in (("train", "samples/s", 64), ("c5", "evals/s", 32), ("c5_train", "samples/s", 32), ("c2b", "evals/s", 4096)):
         assert leg in d, leg
