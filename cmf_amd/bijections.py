@@ -178,9 +178,7 @@ class AffineCouplingBijection(Bijection):
         view, maps = self.view(z.device), self.maps(z.device)
         zb = z.clone()
         # ``nc_hint``: primal-only pass (T is None) whose activations a later tangent sweep with that many column slots reads
-        import types
-        acts_for = T if T is not None or nc_hint is None else types.SimpleNamespace(nc=int(nc_hint))
-        y, g, acts = E.net_primal(self.net, z, view, need_acts=E.train_acts_mode(self.net, view, z.shape[0], acts_for))
+        y, g, acts = E.net_primal(self.net, z, view, need_acts=E.train_acts_mode(self.net, view, z.shape[0], T, nc=nc_hint))
         saved = V = YT = None
         if T is not None:
             saved = []

@@ -144,6 +144,11 @@ __global__ void accumulate_kernel(float* __restrict__ dst, const float* __restri
   }
 }
 
+__global__ void accumulate_scalar_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n) {
+  const long long stride = (long long)gridDim.x * TPB;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
 // acl cross terms (training): the tangent update  out = es (v - zo gs sd) - gt td  also depends on PRIMAL quantities;
 // their cotangents are column reductions of c . d(out)/d(.) -- one wavefront per (sample, modified element):
 //   d s  = -sum_col c es (v - zo gs sd)     d zo = -sum_col c es gs sd
@@ -414,7 +419,13 @@ int cmf_acl_primal_backward(float* dx, long long dx_b, const float* z, long long
 }
 
 int cmf_accumulate(float* dst, const float* src, long long n, void* stream) {
-  if (!dst || !src || n <= 0 || n % 4 || ((uintptr_t)dst | (uintptr_t)src) % 16) return CMF_EINVAL;
+  if (!dst || !src || n <= 0) return CMF_EINVAL;
+  if (n % 4 || ((uintptr_t)dst | (uintptr_t)src) % 16) {          // odd sizes / unaligned views (small gradient tensors): scalar sweep
+    const int blocks = (int)(n / TPB + 1 < 16384 ? n / TPB + 1 : 16384);
+    hipLaunchKernelGGL(accumulate_scalar_kernel, dim3(blocks), dim3(TPB), 0, (hipStream_t)stream, dst, src, n);
+    CMF_LAUNCH_CHECK();
+    return 0;
+  }
   const long long n4 = n / 4;
   const int blocks = (int)(n4 / TPB + 1 < 16384 ? n4 / TPB + 1 : 16384);
   hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(TPB), 0, (hipStream_t)stream, dst, src, n4);
@@ -523,6 +534,7 @@ int cmf_elbo_combine(const float* low, const float* logdet, const float* rec, co
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ float red[4];
   float m = 0.f;
   const long long n4 = n >> 2, stride = (long long)gridDim.x * 256;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
@@ -533,14 +545,18 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(out), __builtin_bit_cast(int, m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // ONE atomic per workgroup: with one per wave (8192 on a 100 MB activation) the launch took 100 us -- a single word takes ~12 ns
+  // per atomic -- against ~20 us for the sweep itself
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<int*>(out), __builtin_bit_cast(int, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 }  // namespace
 
 extern "C" int cmf_absmax(const float* x, long long n, float* out, void* stream) {
   if (!x || !out || n <= 0 || (uintptr_t)x % 16) return CMF_EINVAL;
   const long long blocks = (n / 4 + 255) / 256;
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 1024 ? 1024 : blocks)), dim3(256), 0, (hipStream_t)stream, x, n, out);
   CMF_LAUNCH_CHECK();
   return 0;
 }

@@ -215,6 +215,8 @@ class _PackCache:
         self._store = {}
         self.generation = 0
         self._tables = {}                                          # device -> (signature, descriptor table) of the batched refresh
+        self._lock = threading.RLock()                             # two threads on one device may share the cache
+        self._refreshed = {}                                       # device -> generation its batched refresh last ran for
 
     def invalidate(self):
         """Every cached pack is stale from now on.  Called by writers that change parameter VALUES without touching the
@@ -232,10 +234,15 @@ class _PackCache:
         hit = self._store.get(key)
         if hit is not None and hit[0]() is weight and hit[1] == ver:
             return hit[2]
-        if hit is not None and hit[0]() is weight and hit[1][:4] == ver[:4] and self.BATCHED_REFRESH:
+        if (hit is not None and hit[0]() is weight and hit[1][:4] == ver[:4] and self.BATCHED_REFRESH
+                and self._refreshed.get(weight.device) != self.generation and not torch.cuda.is_current_stream_capturing()):
             # only the generation moved: an optimiser step rewrote the parameter VALUES (FlatOptimizer.step -> invalidate()).
-            # Every pack of the model is stale in the same way: rebuild them all in ONE launch instead of one launch each
-            self._refresh_generation(weight.device)
+            # Every pack of the model is stale in the same way: rebuild them all in ONE launch instead of one launch each --
+            # once per generation and device (entries it had to skip are rebuilt singly below), never inside a graph capture
+            # (the descriptor table is a host -> device copy)
+            with self._lock:
+                self._refresh_generation(weight.device)
+                self._refreshed[weight.device] = self.generation
             hit = self._store.get(key)
             if hit[1] == ver:
                 return hit[2]
@@ -271,10 +278,14 @@ class _PackCache:
         """Re-pack, in one ``cmf_pack_weights_batched`` launch, every entry on ``device`` whose parameter is alive and unchanged
         but for the generation counter (its values were rewritten under it by the fused optimiser step)."""
         todo = []
-        for key, (ref, ver, out, taps) in self._store.items():
+        for key, (ref, ver, out, taps) in list(self._store.items()):     # snapshot: another thread may insert meanwhile
             w = ref()
             if (w is None or ver[4] == self.generation or w.device != device or not w.is_contiguous()
                     or (w._version, w.data_ptr(), w.device, tuple(w.shape)) != ver[:4]):
+                continue
+            if not isinstance(w, nn.Parameter):
+                # a DERIVED tensor (masked MADE weight, L U product: engine.DERIVED): its values are still the old ones until its
+                # own rebuild copies the new ones in (bumping _version); re-packing it now would stamp a stale pack as fresh
                 continue
             todo.append((key, w, ver, out, taps))
         if not todo:
@@ -527,19 +538,14 @@ def relu_bits(act):
 
 
 def accumulate(dst, src):
-    """dst += src (flat fp32 tensors of equal size)."""
+    """dst += src (flat fp32 tensors of equal size; any length / alignment: cmf_accumulate has a scalar sweep for odd ones)."""
     _lib.check(_lib.load().cmf_accumulate(_p(dst), _p(src), min(dst.numel(), src.numel()), _stream()), "cmf_accumulate")
 
 
 def accumulate_any(dst, src):
-    """dst += src for flat fp32 tensors of any length: cmf_tanh_backward with a = 0 computes (dst + src) (1 - 0) in place."""
-    n = dst.numel()
-    assert src.numel() == n
-    if n % 4 == 0 and dst.data_ptr() % 16 == 0 and src.data_ptr() % 16 == 0:
-        return accumulate(dst, src)
-    # odd sizes: elementwise kernel with a broadcast-free formulation: out = (dh + extra) * (1 - a^2) needs a of length n
-    a = torch.zeros(n, dtype=torch.float32, device=dst.device)
-    _lib.check(_lib.load().cmf_tanh_backward(_p(dst), _p(a), _p(src), n, _p(dst), _stream()), "cmf_tanh_backward")
+    """dst += src for flat fp32 tensors of any length (kept as a name: allocates nothing since round 4)."""
+    assert src.numel() == dst.numel()
+    accumulate(dst, src)
 
 
 def stanh_backward(dy, dg, y, g, sw, sb, dsw=None, dsb=None):
@@ -1028,16 +1034,18 @@ class ActList(list):
     grouped = None
 
 
-def train_acts_mode(net, view, B, T=None):
+def train_acts_mode(net, view, B, T=None, nc=None):
     """``need_acts`` for a training forward: "train" (ActList) where every consumer can work from bit masks and grouped floats,
-    else True (per-sample float activations)."""
+    else True (per-sample float activations).  ``T`` = the tangent stack of the sweep that will read the activations, or ``nc``
+    = its column slots when the sweep comes later (primal-only pass)."""
+    nc = T.nc if T is not None else nc
     if net.kind != "resnet" or B % 32 or cfg().primal == "bf16x3":        # (the bf16 split kernel writes no bit masks)
         return True
     conv0 = _resnet_parts(net)[0]
     hid, H, W = conv0.out_channels, view.geom.H, view.geom.W
     if hid % 64 or not _shape_ok_bf16x3(9, hid, W, True, H, hid):
         return True
-    if T is not None and (cfg().tangent != "bf16x3" or T.nc % 32):
+    if nc is not None and (cfg().tangent != "bf16x3" or nc % 32):
         return True
     return "train"
 

@@ -404,7 +404,8 @@ int cmf_tanh_backward(const float* dh, const float* a, const float* extra, long 
  * dz <- dz e^{ls} in place; dz, x: (B, n) with row strides dz_b, x_b.                                                     */
 int cmf_affine_prior_backward(float* dz, long long dz_b, const float* x, long long x_b, const float* log_scale, int n, int B,
                               const float* dlj, float* g_ls, float* g_sh, void* stream);
-/* dst[i] += src[i], n % 4 == 0, 16-byte aligned: the skip connection of the reverse sweep next to the split-precision kernel. */
+/* dst[i] += src[i]: the skip connection of the reverse sweep next to the split-precision kernel (16-byte accesses when n % 4 == 0
+ * and both pointers are 16-byte aligned, a scalar sweep otherwise: odd-sized gradient tensors). */
 int cmf_accumulate(float* dst, const float* src, long long n, void* stream);
 /* relu' bit mask of an activation tensor act (B, C, HW), C % 8 == 0, in the CMF_F_RELU_BITS layout: out[B][HW][C/8] bytes,
  * bit j of byte (b, px, o) = [act(b, 8 o + j, px) > 0].                                                                  */

@@ -237,3 +237,27 @@ def test_rccl_single_rank_runs_the_benchmarks_collectives():
     assert d["ranks_seen"] == 1 and d["n_gpus"] == 1 and d["value"] > 0
     assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert "nccl, 1 rank(s), forced" == d["config"]["process_group"]
+
+
+def test_packs_of_derived_weights_after_an_optimiser_step_are_fresh():
+    """``FlatOptimizer.step`` rewrites the parameters under the tensors' version counters and invalidates the packed
+    copies; the batched re-pack must not stamp a pack of a DERIVED tensor (masked MADE weight, L U product: rebuilt from the new
+    parameters only on its next use) as fresh.  After a step, the model's elbo equals the elbo computed with every cache dropped."""
+    from test_oracle_golden import nsf_model
+    from cmf_amd import engine as E
+    from cmf_amd.optim import FlatOptimizer
+    cfg, schema, shape, dens, sd, sdo, ops = nsf_model("hepmass", 2, (32, 32))
+    dens = dens.cuda().train()
+    opt = FlatOptimizer(dens.parameters(), opt="adam", lr=1e-2)
+    gen = torch.Generator().manual_seed(4)
+    x = (torch.randn(32, *shape, generator=gen) * 1.5).cuda()
+    for _ in range(2):
+        opt.zero_grad()
+        (-dens.elbo(x, add_offdiagonal_metric_reg=True)["elbo"].mean()).backward()
+        opt.step()
+    dens.eval()
+    with torch.no_grad():
+        got = dens.elbo(x, add_offdiagonal_metric_reg=True)["elbo"].clone()
+        E.PACKS._store.clear(); E.PACKS._tables.clear(); E.PACKS._refreshed.clear(); E.DERIVED._store.clear()
+        want = dens.elbo(x, add_offdiagonal_metric_reg=True)["elbo"]
+    assert torch.equal(got, want)
