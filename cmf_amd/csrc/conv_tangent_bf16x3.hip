@@ -766,6 +766,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // the next FIRST chunk: every residual load has (PW-1)/PW of a chunk period to land.
   // always_inline: instantiated four ways but called eight times -- left as a call, everything captured by reference
   // (accumulators, fragments) went through scratch and flat memory
+  int g = 0;                                                       // stream chunk index -> LDS stage g & 1
   auto chunk = [&](int stage, int ring_slot, auto FIRST, auto LAST, auto QUAD) __attribute__((always_inline)) {
 #ifdef CMF_DBG_NOMFMA
     if (LAST) {                                    // timing-only build: the MFMA waves only run the tail and the barriers
@@ -854,7 +855,9 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         for (int c = 0; c < CW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       if (FIRST && s == 0 && !FRES) {
+#ifndef CMF_DBG_SPREAD
         wait_res(p, false);
+#endif
         if constexpr (F16) {                                       // the accumulators hold (2^k xscale) x the result
 #pragma unroll
           for (int c = 0; c < CW; ++c) acc[p][c] *= rscale;
@@ -876,17 +879,26 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
           acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[t % BD], ah[s][c], acc[p][c], 0, 0, 0);
         }
       }
+#ifdef CMF_DBG_SPREAD
+      // timing only (wrong results): the item's tail -- per wave 28 stores + 28 residual loads -- spread evenly over ALL chunks of
+      // the item instead of sitting in the last one: pixel p's pair of stores and loads is issued after its MFMAs in chunk
+      // (p mod 8).  The ceiling of any restructuring that de-bursts the tail (second accumulator set, output staging in LDS ...).
+      if (s == KS - 1 && !FRES && (p & 7) == (g & 7)) {
+        store_pixel(cur, p, f32x4{}, f32x4{});
+        init_pixel(nxt, nxt_rrs, p);
+      }
+#else
       if (LAST && s == KS - 1 && !FRES) {
         store_pixel(cur, p, f32x4{}, f32x4{});
         init_pixel(nxt, nxt_rrs, p);
       }
+#endif
       // keep this step's reads-then-MFMAs(-then-tail) order: without the fence hipcc's scheduler re-clusters the
       // ds_reads next to their uses (lgkmcnt(0) before most MFMA groups) and the ring no longer hides LDS latency
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  int g = 0;                                                       // stream chunk index -> LDS stage g & 1
   if constexpr (!FRES) {
 #pragma unroll
     for (int p = 0; p < PW; ++p) init_pixel(cur, nxt_rrs, p);
