@@ -94,14 +94,17 @@ class KernelConfig:
              as few mask flips as exact fp32 products, profiles/r04_primal_precision_study.txt) at the bf16 MFMA rate;
              "f32" = exact fp32 MFMA (2.8x slower); "bf16x3" = bf16 split (~2^-16: ~15x more mask flips, median per-sample
              log-det / g_ij error 3e-6 / 1.4e-5 instead of 1e-6 / 2e-7 -- kept as an experiment, never the default)."""
-    __slots__ = ("tangent", "primal")
+    __slots__ = ("tangent", "primal", "primal_min_items")
 
-    def __init__(self, tangent="bf16x3", primal="f16x3"):
+    def __init__(self, tangent="bf16x3", primal="f16x3", primal_min_items=96):
         assert tangent in ("bf16x3", "f32") and primal in ("f16x3", "f32", "bf16x3")
         self.tangent, self.primal = tangent, primal
+        #: launches of the fp16 split primal kernel with fewer (tile, sample group) work items than this use the fp32 kernel's
+        #: small-grid forms instead (``_resnet_primal_grouped``)
+        self.primal_min_items = int(primal_min_items)
 
     def __repr__(self):
-        return f"KernelConfig(tangent={self.tangent!r}, primal={self.primal!r})"
+        return f"KernelConfig(tangent={self.tangent!r}, primal={self.primal!r}, primal_min_items={self.primal_min_items})"
 
 
 _DEFAULT_CONFIG = KernelConfig()
@@ -118,7 +121,9 @@ class scope:
     """``with scope(config):`` -- kernels launched by THIS thread inside the block use ``config`` (re-entrant, nestable)."""
 
     def __init__(self, config=None, **kw):
-        self.config = config if config is not None else KernelConfig(**{**{"tangent": cfg().tangent, "primal": cfg().primal}, **kw})
+        cur = cfg()
+        self.config = config if config is not None else KernelConfig(
+            **{**{"tangent": cur.tangent, "primal": cur.primal, "primal_min_items": cur.primal_min_items}, **kw})
 
     def __enter__(self):
         if not hasattr(_tls, "cfg"):
@@ -1061,8 +1066,13 @@ def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts
     new = lambda: torch.empty(G * hid * HW * 16, dtype=torch.float32, device=dev)
     train = need_acts == "train"                          # ActList: the "bits" form + the grouped floats
     prec = cfg().primal
-    if prec == "f16x3" and hid % 64:
-        prec = "f32"                                        # the fp16 split kernel works on whole 64-channel groups
+    if prec == "f16x3":
+        # the fp16 split kernel works on whole 64-channel groups, one persistent workgroup per CU streaming (tile, sample group)
+        # items: below ~100 items (a 32-sample CIFAR shard: 64; the 14 x 14 layers of a 64-sample MNIST shard: 28) the launch is one
+        # item's latency either way and the fp32 kernel's small-grid forms (16 / 32 channels per workgroup) are as fast
+        tiles = (H // 2) * (W // 14) if W % 14 == 0 else (H // 4) * (W // 8)
+        if hid % 64 or G * tiles < cfg().primal_min_items:
+            prec = "f32"
     bits = (need_acts == "bits" or train) and prec != "bf16x3" and hid % 16 == 0
     a = primal_regroup(a0, True)
     acts, masks = [a], []

@@ -145,7 +145,7 @@ def test_relu_mask_flips_of_the_f16x3_primal_against_the_float64_oracle():
             want = [(a > 0) for a in acts64[1:-1]]                    # the activations whose masks the tangent pass reads as bits
             flips32cpu += sum(int(((a32 > 0) != w).sum()) for a32, w in zip(acts32[1:-1], want))
             for prec in ("f16x3", "f32"):
-                with E.scope(primal=prec):
+                with E.scope(primal=prec, primal_min_items=0):      # 16 samples are ONE sample group: below the small-grid cut-over
                     y, gg, acts = E.net_primal(m.net, zf, view, need_acts="bits")
                 masks = [a for a in acts if isinstance(a, E.BitMask)]
                 assert len(masks) == len(want)
@@ -181,7 +181,7 @@ def test_kernel_config_is_per_head_and_thread_local():
     dens_a = dens_a.cuda().eval()
     dens_b = copy.deepcopy(dens_a)
     ha, hb = find_head(dens_a), find_head(dens_b)
-    ha.kernels = E.KernelConfig(tangent="bf16x3", primal="f16x3")
+    ha.kernels = E.KernelConfig(tangent="bf16x3", primal="f16x3", primal_min_items=0)
     hb.kernels = E.KernelConfig(tangent="f32", primal="f32")
     assert E.cfg().tangent == "bf16x3" and E.cfg().primal == "f16x3"           # the defaults, untouched by the heads
     gen = torch.Generator().manual_seed(9)
@@ -261,3 +261,23 @@ def test_packs_of_derived_weights_after_an_optimiser_step_are_fresh():
         E.PACKS._store.clear(); E.PACKS._tables.clear(); E.PACKS._refreshed.clear(); E.DERIVED._store.clear()
         want = dens.elbo(x, add_offdiagonal_metric_reg=True)["elbo"]
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["c3_mnist_full", "c3_mnist_full_cond"])
+def test_full_size_reference_vectors_through_the_grouped_primal_path(name):
+    """The full-size fixtures hold B = 2 samples, and batches that are not a multiple of 16 take the plain primal path; repeated
+    64-fold (128 samples: 8 sample groups, above the small-grid cut-over) the same inputs run through the fp16-split primal kernels
+    and must reproduce the reference's vectors -- also on the conditioned model (cond(J^T J) ~ 6e2, ScaledTanh gains x 2.5)."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    rep = 64
+    x = (g["x"] + g["noise"]).repeat(rep, 1, 1, 1).cuda()
+    with E.timing(lambda n: n.endswith("_primal")) as timer, torch.no_grad():
+        out = inner(dens, True).elbo(x, add_offdiagonal_metric_reg=True)["elbo"]
+    assert timer.by_name(), "the grouped primal path did not run"
+    gr = head.last_gram
+    for i in range(0, 2 * rep, 2):                                     # every copy, bit for bit the same and equal to the fixture
+        assert torch.equal(out[i:i + 2], out[0:2])
+    assert rel(out[0:2], g["elbo_0"] if "elbo_0" in g else g["elbo"]) < 1e-4
+    assert rel(gr.logdet[0:2].view(-1, 1), g["logdet"]) < 1e-4 and rel(gr.jtj[0:2], g["jtj"]) < 1e-4
