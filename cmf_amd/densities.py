@@ -699,6 +699,7 @@ class _ElboFunction(torch.autograd.Function):
     def forward(ctx, head, x, kw, pre, box, *params):
         elbo, state = head.train_forward(x, pre_logjac=pre, **kw)
         ctx.head, ctx.state, ctx.params = head, state, params
+        ctx.timer = E._timer()                             # autograd calls backward on its own thread
         box["prior-dict"] = state["prior_dict"]            # same keys / nesting as the no-grad path (head.nested_prior_dict too)
         return elbo
 
@@ -708,7 +709,8 @@ class _ElboFunction(torch.autograd.Function):
             raise RuntimeError("cmf_amd: backward through this elbo a second time: the saved tangent state (the bulk of the step's "
                                "memory) is released after the first backward; retain_graph / double backward are not supported -- "
                                "call elbo() again")
-        grads = ctx.head.train_backward(ctx.state, d_elbo)
+        with E._use_timer(ctx.timer):
+            grads = ctx.head.train_backward(ctx.state, d_elbo)
         ctx.state = None                                   # the saved tangents are the bulk of the step's memory
         return (None, None, None, None, None, *[grads.get(p) for p in ctx.params])
 

@@ -140,6 +140,23 @@ def _timer():
     return getattr(_tls, "timer", None)
 
 
+class _use_timer:
+    """Install an existing KernelTimer (or None) on the calling thread: autograd runs ``backward`` on its own thread, and the
+    timer that was active when the elbo was computed should see the backward kernels too (tools/bench_train.py)."""
+
+    def __init__(self, timer):
+        self.timer = timer
+
+    def __enter__(self):
+        self.prev = _timer()
+        _tls.timer = self.timer
+        return self.timer
+
+    def __exit__(self, *exc):
+        _tls.timer = self.prev
+        return False
+
+
 class timing:
     """``with timing(select) as t:`` -- launches of THIS thread whose family name ``select`` accepts are bracketed by HIP
     events on the launch stream; ``t.by_name()`` / ``t.summary()`` synchronise once (bench.py's roofline / stages legs)."""

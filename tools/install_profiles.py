@@ -30,6 +30,7 @@ if os.path.exists(os.path.join(src, "c5_train_variants.txt")):
         "# mode = column slots of the low-rank sweep (HUTCH_LOWRANK_NC) or the d-column backward of rounds 1-2)\n" + "".join(lines))
     copied.append(f"{pre}_c5_train_variants.txt")
 cp(os.path.join(src, "mfma_sustained.txt"), f"{pre}_mfma_sustained.txt")
+cp(os.path.join(src, "stage_table.txt"), f"{pre}_stage_table.txt")
 if os.path.exists(os.path.join(src, "gpu_tests.log")):
     open(os.path.join(dst, f"{pre}_gpu_tests_summary.txt"), "w").write("".join(open(os.path.join(src, "gpu_tests.log")).readlines()[-3:]))
     copied.append(f"{pre}_gpu_tests_summary.txt")
