@@ -43,6 +43,7 @@ class ConvPrimalArgs(C.Structure):
 
 
 MLP_MAX_LAYERS = 8
+WGRAD_MAX_BATCH = 16
 
 
 class MlpCouplerArgs(C.Structure):
@@ -67,6 +68,7 @@ SIGNATURES = {
     "cmf_conv_tangent_wgrad_ws": (_ll, [C.POINTER(ConvTangentArgs)]),
     "cmf_conv_tangent_wgrad": (_i, [C.POINTER(ConvTangentArgs), _fp, _fp, _fp, _ll, _fp]),
     "cmf_conv_tangent_wgrad_bf16x3": (_i, [C.POINTER(ConvTangentArgs), _fp, _fp, _fp, _ll, _fp]),
+    "cmf_conv_tangent_wgrad_bf16x3_batched": (_i, [C.POINTER(ConvTangentArgs), _i, C.POINTER(_fp), C.POINTER(_fp), C.POINTER(_fp), _fp, _ll, _fp]),
     "cmf_primal_regroup": (_i, [_fp, _fp, _i, _ll, _i, _fp]),
     "cmf_conv_primal": (_i, [C.POINTER(ConvPrimalArgs), _fp]),
     "cmf_acl_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),

@@ -69,9 +69,22 @@ struct Raw4 {
   float f[4];
   bool ok;                                           // wave-uniform: column and row inside the image
 };
+// Several problems of ONE shape in one launch (cmf_conv_tangent_wgrad_bf16x3_batched): the weight gradients of the 16 hidden primal
+// convs of a coupler at a training shard's 2 - 4 sample groups are 28 - 56 image rows each -- 28 - 56 of 256 workgroups busy, 38 - 43 us
+// per launch, 320 launches per step.  Problem p owns workgroups [p wgp, (p + 1) wgp): the row dealing below runs inside that range.
+struct WgBatch {
+  const float* x[CMF_WGRAD_MAX_BATCH];
+  const float* gy[CMF_WGRAD_MAX_BATCH];
+  float* dw[CMF_WGRAD_MAX_BATCH];
+  int wgp;                                           // workgroups per problem (a multiple of 8: the XCD dealing stays aligned)
+};
+
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_tangent_args a, const float* __restrict__ gy,
-                                                                     float* __restrict__ ws, int co0, int ci0, int nrows) {
+__global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_tangent_args a, WgBatch P, float* __restrict__ ws,
+                                                                     int co0, int ci0, int nrows) {
+  const int prob = blockIdx.x / P.wgp;
+  a.x = P.x[prob];
+  const float* __restrict__ gy = P.gy[prob];
   constexpr bool BITS = MODE == 3, HASF = MODE == 1 || BITS, SELF = MODE == 2;   // BITS: relu' from a bit mask (CMF_F_RELU_BITS)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -87,12 +100,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_ta
   // algorithmic).  Speed only: any dealing covers every row exactly once.
   int xstart, xlen, nbx, jx;
   {
-    const int G = gridDim.x, P = G < 8 ? G : 8, bid = blockIdx.x, xcd = bid % P;
-    const int q = nrows / P, rem = nrows % P;
+    const int G = P.wgp, NX = G < 8 ? G : 8, bid = blockIdx.x - prob * P.wgp, xcd = bid % NX;
+    const int q = nrows / NX, rem = nrows % NX;
     xstart = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
     xlen = q + (xcd < rem ? 1 : 0);
-    nbx = (G - xcd + P - 1) / P;
-    jx = bid / P;
+    nbx = (G - xcd + NX - 1) / NX;
+    jx = bid / NX;
   }
   const int my_rows = jx < xlen ? (xlen - jx + nbx - 1) / nbx : 0;
   const int nslots = my_rows * (W + 1);
@@ -284,10 +297,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3x3_roles_kernel(cmf_conv_ta
 }
 
 // dw[(co0 + co)][ci0 + ci][tap] += sum_wg ws[wg][co][ci][tap]   (fixed order; same as conv_wgrad.hip)
-__global__ __launch_bounds__(256) void wgrad_reduce_split_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nwg, int co0,
+__global__ __launch_bounds__(256) void wgrad_reduce_split_kernel(const float* __restrict__ ws, WgBatch P, int nwg, int co0,
                                                                  int ci0, int cin) {
   const int e = blockIdx.x * 256 + threadIdx.x, per = 64 * 64 * 9;
   if (e >= per) return;
+  ws += (size_t)blockIdx.y * nwg * per;               // problem blockIdx.y: its workgroups' partial blocks
+  float* __restrict__ dw = P.dw[blockIdx.y];
   const int tap = e % 9, ci = (e / 9) % 64 + ci0, co = e / (9 * 64) + co0;
   // eight independent partial sums (the loads of one chain would each wait for the previous add), combined in a fixed order
   float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -302,22 +317,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_split_kernel(const float* __
 
 }  // namespace
 
-extern "C" int cmf_conv_tangent_wgrad_bf16x3(const cmf_conv_tangent_args* a, const float* gy, float* dw, float* ws,
-                                             long long ws_bytes, void* stream) {
-  if (!a || !a->x || !gy || !dw || !ws) return CMF_EINVAL;
+static int wgrad_split_launch(const cmf_conv_tangent_args* a, int nprob, const float* const* xs, const float* const* gys,
+                              float* const* dws, float* ws, long long ws_bytes, void* stream) {
+  if (!a || !ws || nprob < 1 || nprob > CMF_WGRAD_MAX_BATCH) return CMF_EINVAL;
   if (a->taps != 9 || a->cin % 64 || a->cout % 64 || a->nc <= 0 || a->nc % 32) return CMF_EINVAL;
   if (a->np <= 0 || a->H <= 0 || a->W <= 0) return CMF_EINVAL;
   if (a->fmode != CMF_F_NONE && a->fmode != CMF_F_RELU && a->fmode != CMF_F_SELF_RELU && a->fmode != CMF_F_RELU_BITS) return CMF_EINVAL;
-  if ((a->fmode == CMF_F_RELU || a->fmode == CMF_F_RELU_BITS) && (!a->f || a->f_group > 1)) return CMF_EINVAL;
+  if ((a->fmode == CMF_F_RELU || a->fmode == CMF_F_RELU_BITS) && (!a->f || a->f_group > 1 || nprob > 1)) return CMF_EINVAL;
   if (a->fmode == CMF_F_RELU_BITS && a->f_np < (long long)a->H * a->W * (a->cin / 8)) return CMF_EINVAL;   // f_np in bytes
   if (ws_bytes < (long long)WG_MAX * 64 * 64 * 9 * (long long)sizeof(float)) return CMF_EINVAL;
-  if (((uintptr_t)a->x | (uintptr_t)gy) % 16 || (a->x_np | a->x_ci | a->x_px | a->x_sl | a->y_np | a->y_co | a->y_px | a->y_sl) % 4)
-    return CMF_EINVAL;
+  if ((a->x_np | a->x_ci | a->x_px | a->x_sl | a->y_np | a->y_co | a->y_px | a->y_sl) % 4) return CMF_EINVAL;
+  WgBatch P;
+  for (int p = 0; p < CMF_WGRAD_MAX_BATCH; ++p) {
+    const int q = p < nprob ? p : 0;
+    if (!xs[q] || !gys[q] || !dws[q] || ((uintptr_t)xs[q] | (uintptr_t)gys[q]) % 16) return CMF_EINVAL;
+    P.x[p] = xs[q], P.gy[p] = gys[q], P.dw[p] = dws[q];
+  }
   const long long nrows = (long long)a->np * (a->nc / 32) * a->H;
   if (nrows > 0x7fffffffLL / (a->W + 2)) return CMF_ERANGE;
   if ((long long)a->W * a->x_px > 0x7fffffffLL || (long long)a->W * a->y_px > 0x7fffffffLL || (long long)a->W * a->f_px > 0x7fffffffLL)
     return CMF_ERANGE;                                             // the producers form column * pixel-stride in 32 bits
-  const int grid = (int)(nrows < WG_MAX ? nrows : WG_MAX);
+  // one problem: up to WG_MAX workgroups; a batch: WG_MAX / nprob each, rounded down to a multiple of 8 (at least 8)
+  int wgp = nprob == 1 ? (int)(nrows < WG_MAX ? nrows : WG_MAX) : (WG_MAX / nprob) & ~7;
+  if (nprob > 1 && wgp < 8) return CMF_EINVAL;
+  P.wgp = wgp;
+  const int grid = wgp * nprob;
   hipStream_t s = (hipStream_t)stream;
   {                                                                // per (device, kernel) memo: runtime.hip
     hipError_t e = cmf_set_dynamic_lds((const void*)conv_wgrad3x3_roles_kernel<0>, LDS_BYTES);
@@ -329,16 +353,32 @@ extern "C" int cmf_conv_tangent_wgrad_bf16x3(const cmf_conv_tangent_args* a, con
   for (int co0 = 0; co0 < a->cout; co0 += 64)
     for (int ci0 = 0; ci0 < a->cin; ci0 += 64) {
       if (a->fmode == CMF_F_RELU_BITS)
-        hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<3>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
+        hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<3>, dim3(grid), dim3(512), LDS_BYTES, s, *a, P, ws, co0, ci0, (int)nrows);
       else if (a->fmode == CMF_F_RELU)
-        hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<1>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
+        hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<1>, dim3(grid), dim3(512), LDS_BYTES, s, *a, P, ws, co0, ci0, (int)nrows);
       else if (a->fmode == CMF_F_SELF_RELU)
-        hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<2>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
+        hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<2>, dim3(grid), dim3(512), LDS_BYTES, s, *a, P, ws, co0, ci0, (int)nrows);
       else
-        hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<0>, dim3(grid), dim3(512), LDS_BYTES, s, *a, gy, ws, co0, ci0, (int)nrows);
+        hipLaunchKernelGGL(conv_wgrad3x3_roles_kernel<0>, dim3(grid), dim3(512), LDS_BYTES, s, *a, P, ws, co0, ci0, (int)nrows);
       CMF_LAUNCH_CHECK();
-      hipLaunchKernelGGL(wgrad_reduce_split_kernel, dim3(cmf_ceil_div(64 * 64 * 9, 256)), dim3(256), 0, s, ws, dw, grid, co0, ci0, a->cin);
+      hipLaunchKernelGGL(wgrad_reduce_split_kernel, dim3(cmf_ceil_div(64 * 64 * 9, 256), nprob), dim3(256), 0, s, ws, P, wgp, co0, ci0, a->cin);
       CMF_LAUNCH_CHECK();
     }
   return 0;
+}
+
+extern "C" int cmf_conv_tangent_wgrad_bf16x3(const cmf_conv_tangent_args* a, const float* gy, float* dw, float* ws,
+                                             long long ws_bytes, void* stream) {
+  if (!a || !a->x || !gy || !dw) return CMF_EINVAL;
+  const float* xs[1] = {a->x};
+  const float* gys[1] = {gy};
+  float* dws[1] = {dw};
+  return wgrad_split_launch(a, 1, xs, gys, dws, ws, ws_bytes, stream);
+}
+
+extern "C" int cmf_conv_tangent_wgrad_bf16x3_batched(const cmf_conv_tangent_args* a, int nprob, const float* const* x,
+                                                     const float* const* gy, float* const* dw, float* ws, long long ws_bytes,
+                                                     void* stream) {
+  if (!x || !gy || !dw) return CMF_EINVAL;
+  return wgrad_split_launch(a, nprob, x, gy, dw, ws, ws_bytes, stream);
 }

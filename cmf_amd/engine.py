@@ -449,6 +449,39 @@ def conv_tangent_wgrad(x_t, x_off, x_np, x_ci, x_px, gy_t, gy_off, y_np, y_co, y
                4.0 * px * (cin + cout), launch)
 
 
+def conv_tangent_wgrad_batched(xs, gys, dws, x_np, x_ci, x_px, y_np, y_co, y_px, np_, cin, cout, H, W, nc, fmode=F_NONE, x_sl=16, y_sl=16):
+    """``conv_tangent_wgrad`` for up to 16 problems of ONE shape (lists of input tensors, cotangent tensors and weight-gradient
+    tensors) in one launch of the split-precision kernel: the 256 persistent workgroups are split over the problems.  For launches
+    that are a few dozen image rows each (the primal weight gradients of a coupler at a training shard's sample groups)."""
+    lib = _lib.load()
+    n = len(xs)
+    assert n == len(gys) == len(dws) and 1 <= n <= _lib.WGRAD_MAX_BATCH and fmode in (F_NONE, F_SELF_RELU)
+    assert cin % 64 == 0 and cout % 64 == 0 and nc % 32 == 0
+    a = ConvTangentArgs()
+    a.x = _p(xs[0]); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
+    a.fmode = fmode
+    a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
+    a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), 9
+    a.f_group = 1
+    a.x_sl, a.y_sl = int(x_sl), int(y_sl)
+    need = int(lib.cmf_conv_tangent_wgrad_ws(C.byref(a)))
+    key = (xs[0].device, torch.cuda.current_stream().cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _WGRAD_WS[key] = torch.empty(need // 4, dtype=torch.float32, device=xs[0].device)
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    for dw in dws:
+        assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * cin * 9
+    launch = lambda: _lib.check(lib.cmf_conv_tangent_wgrad_bf16x3_batched(C.byref(a), n, arr(xs), arr(gys), arr(dws), _p(ws), need, _stream()),
+                                "cmf_conv_tangent_wgrad_bf16x3_batched")
+    TIMER = _timer()
+    if TIMER is None:
+        return launch()
+    px = float(H) * W * nc * np_ * n
+    TIMER.wrap(f"conv_wgrad_t9_ci{cin}_co{cout}" + ("_primal" if fmode == F_SELF_RELU else "") + "_batched", 2.0 * cin * cout * 9 * px,
+               4.0 * px * (cin + cout), launch)
+
+
 def primal_regroup(t, to_grouped):
     """(B, N) <-> (B/16, N, 16): sample-grouped layout used to run primal data through the tangent kernels."""
     B = t.shape[0] if to_grouped else t.shape[0] * 16
@@ -1374,9 +1407,25 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
     pn = lambda c: (c * HW * 16, HW * 16, 16)
     new = lambda c: torch.empty(G * c * HW * 16, dtype=torch.float32, device=dev)
 
+    # The 2 K hidden weight gradients of the coupler are independent of each other once their operands exist: they are collected and
+    # launched TOGETHER (cmf_conv_tangent_wgrad_bf16x3_batched) when one of them alone would leave most of the chip idle -- at a
+    # training shard's 2 - 4 sample groups a problem is 28 - 56 image rows for 256 persistent workgroups (13.7 ms in 320 launches of
+    # 43 us per C3 step at 64 samples, 12 ms per C5 step at 32)
+    gs = hid * HW * 16                                  # group stride = slice stride
+    batch_wgrads = pair and (G // 2) * H < 256 and hid == 64
+    pending = []
+
+    def flush_wgrads():
+        for i in range(0, len(pending), _lib.WGRAD_MAX_BATCH):
+            part = pending[i:i + _lib.WGRAD_MAX_BATCH]
+            conv_tangent_wgrad_batched([p[0] for p in part], [p[1] for p in part], [p[2] for p in part], 2 * gs, HW * 16, 16,
+                                       2 * gs, HW * 16, 16, G // 2, hid, hid, H, W, 32, fmode=F_SELF_RELU, x_sl=gs, y_sl=gs)
+        pending.clear()
+
     def hidden_wgrad(x_g, gy_g, weight):               # 3x3, hid -> hid, the input's own relu
-        if pair:
-            gs = hid * HW * 16                            # group stride = slice stride
+        if batch_wgrads:
+            pending.append((x_g, gy_g, _grad_of(grads, weight)))       # the tensors stay alive until the flush
+        elif pair:
             conv_tangent_wgrad(x_g, 0, 2 * gs, HW * 16, 16, gy_g, 0, 2 * gs, HW * 16, 16, _grad_of(grads, weight), 9, G // 2, hid, hid,
                                H, W, 32, fmode=F_SELF_RELU, x_sl=gs, y_sl=gs)
         else:
@@ -1406,6 +1455,7 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
         da2 = new(hid)
         conv_tangent(dc1, 0, *pn(hid), blk.conv1.weight, 9, da2, *pn(hid), G, hid, hid, H, W, 16, res_t=da, **self_fo(a_in), **tr)
         da = da2
+    flush_wgrads()
     # a_0 = conv0(mask . z[view])   (no bias)
     cin, m = view.cin, view.mask
     rows = z.reshape(B, geo.C, HW)[:, view.chan_off::view.chan_step][:, :cin]

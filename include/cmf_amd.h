@@ -161,6 +161,14 @@ int cmf_conv_tangent_wgrad(const cmf_conv_tangent_args* a, const float* gy, floa
  * anything else: CMF_EINVAL, use cmf_conv_tangent_wgrad.  Same arguments and workspace.                                      */
 int cmf_conv_tangent_wgrad_bf16x3(const cmf_conv_tangent_args* a, const float* gy, float* dw, float* ws, long long ws_bytes,
                                   void* stream);
+/* nprob <= CMF_WGRAD_MAX_BATCH problems of ONE shape in one launch: x[p], gy[p], dw[p] are HOST arrays of device pointers (a->x is
+ * ignored; everything else -- strides, np, nc, H, W, fmode NONE or SELF_RELU -- is read from `a` and shared).  The 256 persistent
+ * workgroups are split evenly over the problems.  Made for the primal weight gradients of a coupler's hidden convs at a training
+ * shard's few sample groups (trainer.py:213 differentiates 16 such convs per coupler): 28 - 56 image rows per problem leave most of the
+ * chip idle when launched one by one.  Same workspace as the single-problem call. */
+#define CMF_WGRAD_MAX_BATCH 16
+int cmf_conv_tangent_wgrad_bf16x3_batched(const cmf_conv_tangent_args* a, int nprob, const float* const* x, const float* const* gy,
+                                          float* const* dw, float* ws, long long ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Primal convolution / linear layer on fp32 MFMA: nn.Conv2d / nn.Linear forward of the coupler

@@ -281,3 +281,31 @@ def test_full_size_reference_vectors_through_the_grouped_primal_path(name):
         assert torch.equal(out[i:i + 2], out[0:2])
     assert rel(out[0:2], g["elbo_0"] if "elbo_0" in g else g["elbo"]) < 1e-4
     assert rel(gr.logdet[0:2].view(-1, 1), g["logdet"]) < 1e-4 and rel(gr.jtj[0:2], g["jtj"]) < 1e-4
+
+
+@pytest.mark.parametrize("H,W,groups", [(28, 28, 4), (14, 14, 4), (32, 32, 2)])
+def test_batched_primal_weight_gradients_equal_the_single_launches(H, W, groups):
+    """cmf_conv_tangent_wgrad_bf16x3_batched: five problems of one shape (sample groups paired as the two 16-column slices of a
+    32-column "sample", the input's own relu: the primal weight gradients of a coupler's hidden convs) in ONE launch against one
+    launch each -- and both against float64 autograd."""
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(H + groups)
+    C, HW, nprob = 64, H * W, 5
+    B = 16 * groups
+    gs = C * HW * 16
+    xs = [torch.randn(B, C, H, W, generator=gen) for _ in range(nprob)]
+    gys = [torch.randn(B, C, H, W, generator=gen) for _ in range(nprob)]
+    xg = [E.primal_regroup(x.cuda(), True) for x in xs]
+    gg = [E.primal_regroup(g.cuda(), True) for g in gys]
+    single = [torch.zeros(C, C, 3, 3, device="cuda") for _ in range(nprob)]
+    batched = [torch.full((C, C, 3, 3), 0.5, device="cuda") for _ in range(nprob)]            # accumulated INTO
+    for x, g, dw in zip(xg, gg, single):
+        E.conv_tangent_wgrad(x, 0, 2 * gs, HW * 16, 16, g, 0, 2 * gs, HW * 16, 16, dw, 9, groups // 2, C, C, H, W, 32,
+                             fmode=E.F_SELF_RELU, x_sl=gs, y_sl=gs)
+    E.conv_tangent_wgrad_batched(xg, gg, batched, 2 * gs, HW * 16, 16, 2 * gs, HW * 16, 16, groups // 2, C, C, H, W, 32,
+                                 fmode=E.F_SELF_RELU, x_sl=gs, y_sl=gs)
+    for x, g, d1, d2 in zip(xs, gys, single, batched):
+        w = torch.zeros(C, C, 3, 3, dtype=torch.float64, requires_grad=True)
+        (F.conv2d(torch.relu(x).double(), w, padding=1) * g.double()).sum().backward()
+        assert rel(d1, w.grad) < 5e-5 and rel(d2 - 0.5, w.grad) < 5e-5
+        assert rel(d2 - 0.5, d1) < 2e-6                         # the same products, dealt to 48 instead of up to 56 workgroups
