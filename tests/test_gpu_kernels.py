@@ -13,7 +13,7 @@ def rel(a, b):
 
 @pytest.mark.parametrize("cin,cout,H,W,taps,nc", [
     (64, 64, 14, 14, 9, 64), (64, 64, 28, 28, 9, 32), (2, 64, 14, 14, 9, 16), (64, 4, 14, 14, 1, 64),
-    (64, 64, 16, 16, 9, 16), (64, 64, 32, 32, 9, 32), (32, 64, 14, 14, 9, 16), (64, 32, 14, 28, 9, 32), (32, 32, 16, 8, 9, 16),
+    (1, 64, 28, 28, 9, 32), (1, 64, 5, 14, 9, 16), (2, 40, 6, 14, 9, 16), (64, 64, 16, 16, 9, 16), (64, 64, 32, 32, 9, 32), (32, 64, 14, 14, 9, 16), (64, 32, 14, 28, 9, 32), (32, 32, 16, 8, 9, 16),
     (128, 64, 14, 14, 9, 16), (96, 128, 6, 14, 9, 16), (3, 24, 9, 11, 9, 16), (8, 64, 14, 14, 9, 16), (16, 40, 5, 28, 9, 32), (64, 130, 3, 14, 9, 16), (17, 40, 5, 7, 9, 32), (64, 2, 28, 28, 1, 16), (130, 70, 1, 37, 1, 16),
 ])
 @pytest.mark.parametrize("fmode", ["none", "relu", "tanh", "raw"])
