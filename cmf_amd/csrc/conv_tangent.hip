@@ -208,31 +208,6 @@ __global__ __launch_bounds__(256, 2) void conv_tangent_kernel(cmf_conv_tangent_a
     __syncthreads();
     if (ch + 1 < nchunks) prefetch((ch + 1) * CIC);
 
-    if (TAPS == 9 && a.cin <= 2) {
-      // THIN inputs (the first conv of a coupler: 1 -> 64 / 2 -> 64 channels).  With K = 4 CHANNELS of one tap per MFMA, three or two
-      // of the four K lanes multiply padding: 252 MFMAs per wave for 9 (18) real K values, and the launch -- a pure 6.6 GB write at
-      // 28 x 28, B = 512 -- was bound by them (1.77 ms = 3.7 TB/s).  Here the K lanes carry (tap, channel) slots instead: slot
-      // j = 4 step + kq -> tap j / cin, channel j % cin; 3 (5) steps of 28 MFMAs.  Slots past 9 cin read the zero-padded channel 7.
-      const int cin = a.cin, nst = (9 * cin + 3) / 4;
-      const float* xs0 = Xs + cl + ((wrow * C::TWH + wx) * 16);
-      const float* ws0 = Ws + cl;
-      for (int st = 0; st < nst; ++st) {
-        const int j = 4 * st + kq;
-        const bool real = j < 9 * cin;
-        const int tap = real ? (cin == 1 ? j : j >> 1) : 0, ci = real ? (cin == 1 ? 0 : j & 1) : 7;
-        const float* bp = xs0 + ci * C::XS_CI + ((tap / 3) * C::TWH + tap % 3) * 16;
-        const float* ap = ws0 + (tap * CIC + ci) * C::WS_CI;
-        float av[COT];
-#pragma unroll
-        for (int c = 0; c < COT; ++c) av[c] = ap[c * 16];
-#pragma unroll
-        for (int p = 0; p < PXW; ++p) {
-          const float bv = bp[p * 16];
-#pragma unroll
-          for (int c = 0; c < COT; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av[c], acc[p][c], 0, 0, 0);
-        }
-      }
-    } else
 #pragma unroll
     for (int kg = 0; kg < CIC / 4; ++kg) {
       if (ch * CIC + kg * 4 >= a.cin) break;              // all-padding K group (the 1 -> 64 / 2 -> 64 first convs): skip
