@@ -773,7 +773,6 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       for (int c = 0; c < CW; ++c) fw[o][c] = fz.w[o * 64 + cohalf * CW * 16 + c * 16 + cl];
   }
   [[maybe_unused]] auto fuse_rs = cur_yrs;
-  [[maybe_unused]] auto fuse_nxt_rrs = cur_yrs;                    // FUSE: the NEXT item's residual descriptor (zero records past the last item)
   [[maybe_unused]] auto load_fmask = [&](const Item& it) __attribute__((always_inline)) {
     if constexpr (FUSE > 0) {
       {                                                            // this item's yt descriptor: plane of this channel half, sample np
@@ -935,7 +934,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       }
       if (FIRST && s == 0 && !FRES) {
 #ifndef CMF_DBG_SPREAD
-        if constexpr (FUSE == 0) wait_res(p, false);
+        wait_res(p, false);
 #endif
         if constexpr (F16) {                                       // the accumulators hold (2^k xscale) x the result
 #pragma unroll
@@ -968,18 +967,9 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       }
 #else
       if (LAST && s == KS - 1 && !FRES) {
-        if constexpr (FUSE > 0) {
-          // every VMEM operation of this variant's MFMA waves is compiler-visible (builtin loads / stores, hipcc's own waits): with
-          // the asm loads of init_pixel hipcc copied freshly "loaded" accumulators around the longer epilogue before the data had landed
-          fuse_pixel(cur, p);
-#pragma unroll
-          for (int c = 0; c < CW; ++c)
-            acc[p][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                fuse_nxt_rrs, rvoff, nxt.rpix + 4 * (((p / C::TW) * a.W + p % C::TW) * r_px + c * 16 * r_co), 0));
-        } else {
-          store_pixel(cur, p, f32x4{}, f32x4{});
-          init_pixel(nxt, nxt_rrs, p);
-        }
+        if constexpr (FUSE > 0) fuse_pixel(cur, p);
+        else store_pixel(cur, p, f32x4{}, f32x4{});
+        init_pixel(nxt, nxt_rrs, p);
       }
 #endif
       // keep this step's reads-then-MFMAs(-then-tail) order: without the fence hipcc's scheduler re-clusters the
@@ -988,24 +978,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     }
   };
 
-  if constexpr (FUSE > 0) {
-    // FUSE: the FIRST item's residual through compiler-visible loads.  The inline-asm loads of init_pixel complete asynchronously while
-    // hipcc believes their destinations are defined at once; with this variant's longer prologue (per-lane 1x1 weights, lane masks) it
-    // COPIED the first three pixels' accumulators to other registers between the asm loads and the vmcnt(0) below -- before the data
-    // had landed (tests/dev/fused1x1_probe2.py: integers where pixel 0 .. 2 should have been).  Once per launch; the steady-state tail
-    // (init_pixel in the item's last chunk) loads into the registers the stores just read: nothing to copy.
-    const unsigned long long ru = reinterpret_cast<unsigned long long>(
-        a.r + (long long)np_ * a.r_np + (long long)slice_ * (a.r_sl ? a.r_sl : 16) + (long long)cog_ * 64 * r_co);
-    const auto rrs0 = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ru >> 32)) << 32) |
-                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ru)), 0, n_items > 0 ? 0x7fffff00 : 0, RS_FLAGS);
-#pragma unroll
-    for (int p = 0; p < PW; ++p)
-#pragma unroll
-      for (int c = 0; c < CW; ++c)
-        acc[p][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rrs0, rvoff, cur.rpix + 4 * (((p / C::TW) * a.W + p % C::TW) * r_px + c * 16 * r_co), 0));
-  } else if constexpr (!FRES) {
+  if constexpr (!FRES) {
 #pragma unroll
     for (int p = 0; p < PW; ++p) init_pixel(cur, nxt_rrs, p);
   }
@@ -1024,13 +997,6 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       nxt_yrs = y_rsrc(np, slice, cog);
       if constexpr (F16) nxt_mrs = m_rsrc(np, slice, cog);
       nxt_rrs = r_rsrc(np, slice, cog, has_next);                  // last item: zero records, nothing is fetched
-      if constexpr (FUSE > 0) {
-        const unsigned long long ru = reinterpret_cast<unsigned long long>(
-            a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) + (long long)cog * 64 * r_co);
-        fuse_nxt_rrs = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ru >> 32)) << 32) |
-                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ru)), 0, has_next ? 0x7fffff00 : 0, RS_FLAGS);
-      }
     };
     // nchunks = 4 G (launcher precondition): chunks 4m, 4m+1, 4m+2 run two K-steps and park their centre pixels, chunk
     // 4m+3 adds the four-octet centre K-step; the item's first chunk waits for the residual, its last one stores.

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 from cmf_amd import engine as E
 torch.set_printoptions(linewidth=220, precision=2, sci_mode=False)
 H = W = 14
-B, C, nc, n_out = int(sys.argv[1]) if len(sys.argv) > 1 else 1, 64, 16, 2
+B, C, nc, n_out = 1, 64, 16, 2
 HW = H * W
 hd, hsl = (C * HW * nc, 16, C * nc), C * 16
 u = torch.zeros(B * C * HW * nc, device="cuda")
@@ -25,9 +25,7 @@ def run(h5, wf, tag):
     p0 = t.data[:n].view(B, n_out, HW, nc).cpu()
     p1 = t.data[t.plane:t.plane + n].view(B, n_out, HW, nc).cpu()
     ref = torch.einsum("oc,bpscl->bopsl", wf, h5).reshape(B, n_out, HW, nc)
-    err = (p0 + p1 - ref).abs()
-    print(f"== {tag}: max err of the sum {float(err.max()):.3g}; wrong samples {int((err.flatten(1).max(1).values > 1e-3).sum())} of {B}; "
-          f"wrong pixels of sample {B - 1}: {(err[B - 1].amax((0, 2)) > 1e-3).nonzero().flatten().tolist()[:20]}")
+    print(f"== {tag}: max err of the sum {float((p0 + p1 - ref).abs().max()):.3g}")
     for o in range(n_out):
         print(f"  o={o} pixel 0  plane0 {p0[0, o, 0].tolist()}")
         print(f"       pixel 0  plane1 {p1[0, o, 0].tolist()}")
