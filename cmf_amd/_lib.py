@@ -73,8 +73,6 @@ SIGNATURES = {
     "cmf_conv_primal": (_i, [C.POINTER(ConvPrimalArgs), _fp]),
     "cmf_acl_primal": (_i, [_fp, _ll, _fp, _ll, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "cmf_acl_tangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _fp]),
-    "cmf_acl_tangent_planes": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _fp]),
-    "cmf_conv_tangent_bf16x3_fused1x1": (_i, [C.POINTER(ConvTangentArgs), _fp, _i, _fp, _ll, _ll, _ll, _ll, _fp, _ll, _fp]),
     "cmf_acl_cotangent": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _fp]),
     "cmf_acl_primal_backward": (_i, [_fp, _ll, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "cmf_acl_cross_terms": (_i, [_fp, _ll, _ll, _fp, _ll, _ll, _fp, _ll, _ll, _i, _fp, _ll, _fp, _ll, _fp, _fp, _fp, _fp, _i, _i,

@@ -130,26 +130,9 @@ __device__ __forceinline__ int xslot(int col, int pix) { return (((col & 3) << 2
 // (measured: median g_ij error of the full-size model 1.3e-6 against 4e-7).  The accumulators start at zero, the item's last chunk
 // carries no tail, and after it the wave loads the residual into the registers its fragments occupied and adds it ONCE, after the
 // products, like cmf_conv_tangent does.  The round trip is exposed once per item: ~15 % on the 80 launches of a step that have one.
-// FUSE = n (2 or 4; cmf_conv_tangent_bf16x3_fused1x1): the coupler's LAST hidden conv also applies the network's final 1x1 conv
-// (64 -> n channels, with the relu' of the last primal activation as a bit mask) to its own output tile, in the epilogue:
-//   yt(np, o, px, :) = sum_ch Wf[o][ch] [a_K(np, ch, px) > 0] h_K(np, ch, px, :)
-// so the 64-channel tangent h_K -- 6.6 GB at 28 x 28, B = 512, read by nothing else -- is neither written nor re-read (the separate
-// 1x1 launch is a pure HBM read at 5 - 6.6 TB/s: 1.0 - 1.3 ms per 28 x 28 coupler).  A wave holds 32 of the 64 channels in its lanes
-// (lane (kq, cl): 4 columns of channel cl of tile c), so the contraction runs ACROSS lanes: per pixel and output 2 fma per register,
-// then a 16-lane row reduction by DPP (quad_perm, row_half_mirror, row_mirror: 4 v_add_f32_dpp per register); the two channel halves
-// (waves 2 row + 0 / 1) write two partial planes which the coupling update adds (cmf_acl_tangent_planes).
-struct Fuse1x1 {
-  const float* w;                  // Wf [n][64] fp32 (the nn.Conv2d 1x1 weight)
-  float* y;                        // yt partial planes: y + half * plane + np * y_np + o * y_co + px * y_px + column
-  long long plane, y_np, y_co, y_px;
-  const unsigned char* mask;       // relu' bits of a_K (CMF_F_RELU_BITS layout: byte np * mask_np + px * 8 + ch / 8)
-  long long mask_np;
-};
-
-template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false, int FUSE = 0>
+template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false>
 __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
-                                                                       int nslices, int ncog, int total, Fuse1x1 fz) {
-  static_assert(FUSE == 0 || (MODE == 3 && COT == 4 && !F16), "the fused 1x1 epilogue: bit-mask input factor, 64-channel groups");
+                                                                       int nslices, int ncog, int total) {
   static_assert(!F16 || (MODE == 2 && COT == 4), "the fp16 variant is the primal pass: SELF mode, 64-channel groups");
   static_assert(!FRES || F16, "residual-in-the-epilogue is the fp16 variant's");
   // MODE: 0 = general factor formula, 1 = relu factor (2 instead of 6 VALU per channel in the loader), 2 = SELF (the
@@ -593,7 +576,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   const int rvoff = 4 * ((cohalf * CW * 16 + cl) * r_co + kq * 4);
   struct Item {
     int ypix, rpix;                                                // byte offset of pixel p = 0 of this wave's tile row
-    int pix0, np, cog, slice;                                      // (PLAIN / FUSE) pixel index of p = 0, sample, channel group, column slice
+    int pix0, np, cog;                                             // (PLAIN) pixel index of p = 0, sample, channel group: output mask
   };
   auto item_geom = [&](int item, int& np, int& slice, int& cog, Item& it) {
     int tile;
@@ -601,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     const int pix0 = (C::TH * (tile / tiles_x) + wrow) * a.W + C::TW * (tile % tiles_x);
     it.ypix = 4 * pix0 * y_px;
     it.rpix = 4 * pix0 * r_px;
-    it.pix0 = pix0, it.np = np, it.cog = cog, it.slice = slice;
+    it.pix0 = pix0, it.np = np, it.cog = cog;
   };
   // descriptors are built from readfirstlane'd words: hipcc otherwise keeps loop-carried descriptors in VGPRs and
   // wraps every access in a waterfall loop
@@ -763,72 +746,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       __builtin_amdgcn_raw_buffer_store_b32(mbits, cur_mrs, mvoff, (it.pix0 + (p / C::TW) * a.W + p % C::TW) * (a.cout / 8), 0);
     }
   };
-  // FUSE: per-lane weights of this lane's two channels for every output, and the fused pixel epilogue (instead of store_pixel)
-  [[maybe_unused]] float fw[FUSE > 0 ? FUSE : 1][CW];
-  [[maybe_unused]] unsigned fmask[PW];
-  if constexpr (FUSE > 0) {
-#pragma unroll
-    for (int o = 0; o < FUSE; ++o)
-#pragma unroll
-      for (int c = 0; c < CW; ++c) fw[o][c] = fz.w[o * 64 + cohalf * CW * 16 + c * 16 + cl];
-  }
-  [[maybe_unused]] auto fuse_rs = cur_yrs;
-  [[maybe_unused]] auto load_fmask = [&](const Item& it) __attribute__((always_inline)) {
-    if constexpr (FUSE > 0) {
-      {                                                            // this item's yt descriptor: plane of this channel half, sample np
-        const unsigned long long u = reinterpret_cast<unsigned long long>(fz.y + (long long)cohalf * fz.plane + (long long)it.np * fz.y_np);
-        const unsigned lo_ = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
-        const unsigned hi_ = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-        fuse_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi_ << 32) | lo_), 0, 0x7fffff00, RS_FLAGS);
-      }
-      const unsigned long long base = reinterpret_cast<unsigned long long>(fz.mask) + (unsigned long long)it.np * fz.mask_np + (unsigned)(cohalf * 4);
-      const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
-      const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
-      const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
-#pragma unroll
-      for (int p = 0; p < PW; ++p) {
-        const int off = __builtin_amdgcn_readfirstlane((it.pix0 + (p / C::TW) * a.W + p % C::TW) * 8);
-        unsigned w;
-        asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w) : "s"(sb), "s"(off) : "memory");
-        fmask[p] = w;
-      }
-    }
-  };
-  [[maybe_unused]] auto fuse_pixel = [&](const Item& it, int p) __attribute__((always_inline)) {
-    const int slice = it.slice;
-    if constexpr (FUSE > 0) {
-      f32x4 v[CW];
-#pragma unroll
-      for (int c = 0; c < CW; ++c) {
-        const bool on = (fmask[p] >> (c * 16 + cl)) & 1u;
-        v[c] = on ? acc[p][c] : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      const int ysoff = 4 * ((it.pix0 + (p / C::TW) * a.W + p % C::TW) * (int)fz.y_px + slice * 16);
-#pragma unroll
-      for (int o = 0; o < FUSE; ++o) {
-        f32x4 t = v[0] * fw[o][0];
-#pragma unroll
-        for (int c = 1; c < CW; ++c) t += v[c] * fw[o][c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                              // sum over the 16 lanes of the row (the 16 channels of a tile)
-          float x = t[r];
-          x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-          x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-          x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
-          x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
-          t[r] = x;
-        }
-        // lane cl == 0 of every row stores its 4 columns; the others go past the descriptor's range (dropped, counted by vmcnt)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, t), fuse_rs, cl == 0 ? 16 * kq : Y_DROP, ysoff + 4 * o * (int)fz.y_co, 0);
-      }
-    }
-  };
   // Pixel p's residual has landed when at most N VMEM operations issued after it are outstanding.  The tail issues,
   // per pixel, CW stores then CW loads, so after pixel p's loads come 2*CW*(PW-1-p) operations of the same tail
   // (+ 2*CW*p of THIS chunk's tail when the item has a single chunk).
   auto wait_res = [&](int p, bool also_last) __attribute__((always_inline)) {
     static_assert(CW == 2 || CW == 1, "operand list below");
-    constexpr int NT = (FUSE > 0 ? FUSE : CW) + CW + (F16 ? 1 : 0);   // VMEM operations of one pixel's tail (F16: + the mask store; FUSE: one store per output)
+    constexpr int NT = 2 * CW + (F16 ? 1 : 0);                     // VMEM operations of one pixel's tail (F16: + the mask store)
     const int n0 = NT * (PW - 1 - p) + (also_last ? NT * p : 0);
     const int n = n0 > 63 ? 63 : n0;                               // vmcnt is a 6-bit field: waiting for more is always safe
     if constexpr (CW == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(acc[p][0]), "+v"(acc[p][1]) : "n"(n));
@@ -857,7 +780,6 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #endif
     constexpr int KS = QUAD ? 3 : 2, NSTEP = KS * PW;              // step t = KS*p + s (pixel-major)
     if (LAST) load_omask(cur);                                     // PLAIN only: scalar loads, land during this chunk
-    if (LAST) load_fmask(cur);                                     // FUSE only
     const unsigned char* Xh = smem + stage * C::BUF_BYTES;
     const unsigned char* Xl = Xh + C::XS_BYTES;
     const unsigned char* Wh = Xh + 2 * C::XS_BYTES;
@@ -967,8 +889,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       }
 #else
       if (LAST && s == KS - 1 && !FRES) {
-        if constexpr (FUSE > 0) fuse_pixel(cur, p);
-        else store_pixel(cur, p, f32x4{}, f32x4{});
+        store_pixel(cur, p, f32x4{}, f32x4{});
         init_pixel(nxt, nxt_rrs, p);
       }
 #endif
@@ -1133,14 +1054,14 @@ __global__ __launch_bounds__(1024) void pack_f16_scale_kernel(const float* __res
   }
 }
 
-template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false, int FUSE = 0>
-int launch(const cmf_conv_tangent_args& a, hipStream_t s, const Fuse1x1& fz = Fuse1x1{}) {
+template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false>
+int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   using C = BCfg<COT, PXW>;
   const int tiles_x = cmf_ceil_div(a.W, C::TW), tiles = tiles_x * cmf_ceil_div(a.H, C::TH);
   const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
-  auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE, F16, FRES, FUSE>;
+  auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE, F16, FRES>;
   constexpr int lds = C::LDS_BYTES;
   if (hipError_t e = cmf_set_dynamic_lds((const void*)k, lds); e != hipSuccess) return (int)e;   // per device (runtime.hip)
   const int n_cu = cmf_device_cus();
@@ -1148,7 +1069,7 @@ int launch(const cmf_conv_tangent_args& a, hipStream_t s, const Fuse1x1& fz = Fu
 #ifdef CMF_DBG_STAMP
   if (const char* e = getenv("CMF_DBG_GRID")) grid = atoi(e) < grid ? atoi(e) : grid;   // diagnostic: fewer active CUs
 #endif
-  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles, nslices, ncog, (int)total, fz);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a, tiles_x, tiles, nslices, ncog, (int)total);
   CMF_LAUNCH_CHECK();
   return 0;
 }
@@ -1268,33 +1189,4 @@ extern "C" int cmf_conv_tangent_f16x3(const cmf_conv_tangent_args* ap, void* str
   hipStream_t s = (hipStream_t)stream;
   if (a.r) return t14 ? launch<4, 7, 2, true, true>(a, s) : launch<4, 4, 2, true, true>(a, s);
   return t14 ? launch<4, 7, 2, true>(a, s) : launch<4, 4, 2, true>(a, s);
-}
-
-extern "C" int cmf_conv_tangent_bf16x3_fused1x1(const cmf_conv_tangent_args* ap, const float* w1x1, int n_out, float* yt,
-                                                long long yt_plane, long long yt_np, long long yt_co, long long yt_px,
-                                                const void* mask, long long mask_np, void* stream) {
-  if (!ap || !w1x1 || !yt || !mask) return CMF_EINVAL;
-  cmf_conv_tangent_args a = *ap;
-  if (!a.x || !a.w || a.np <= 0 || a.cin <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
-  if (n_out != 2 && n_out != 4) return CMF_EINVAL;
-  if (a.taps != 9 || a.cin % 32 || a.cout != 64 || a.nc <= 0 || a.nc % 16) return CMF_EINVAL;
-  if (a.fmode != CMF_F_RELU_BITS || !a.f || a.fo || a.bias || a.mask_out) return CMF_EINVAL;
-  if (a.f_np < (long long)a.H * a.W * (a.cin / 8) || mask_np < (long long)a.H * a.W * 8) return CMF_EINVAL;
-  if ((a.x_np | a.x_ci | a.x_px | a.x_sl | a.r_sl) % 4 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return CMF_EINVAL;
-  if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;
-  if ((yt_plane | yt_np | yt_co | yt_px) % 4 || (uintptr_t)yt % 16 || (uintptr_t)mask % 4 || mask_np % 4) return CMF_EINVAL;
-  const long long HW = (long long)a.H * a.W;
-  if (!fits_int((a.cin + 8) * a.x_ci + HW * a.x_px + a.nc) || (a.r && !fits_int(128 * a.r_co + HW * a.r_px + a.nc)) ||
-      !fits_int(n_out * yt_co + HW * yt_px + a.nc + 64) || HW > (1 << 24))
-    return CMF_ERANGE;
-  const bool t14 = a.W % 14 == 0 && a.H % 2 == 0, t8 = a.W % 8 == 0 && a.H % 4 == 0;
-  if (!(t14 || t8)) return CMF_EINVAL;
-  // the 64-channel output itself is NOT written: the store path is replaced by the contraction.  The kernel still wants a valid y
-  // pointer for its (unused) descriptors: point it at x
-  a.y = const_cast<float*>(a.x);
-  a.y_np = a.y_co = a.y_px = a.y_sl = 0;
-  Fuse1x1 fz{w1x1, yt, yt_plane, yt_np, yt_co, yt_px, reinterpret_cast<const unsigned char*>(mask), mask_np};
-  hipStream_t s = (hipStream_t)stream;
-  if (n_out == 2) return t14 ? launch<4, 7, 3, false, false, 2>(a, s, fz) : launch<4, 4, 3, false, false, 2>(a, s, fz);
-  return t14 ? launch<4, 7, 3, false, false, 4>(a, s, fz) : launch<4, 4, 3, false, false, 4>(a, s, fz);
 }

@@ -65,7 +65,7 @@ __global__ void acl_tangent_kernel(float* __restrict__ t, long long t_b, long lo
                                    long long yt_b, long long yt_r, int nc4, const float* __restrict__ z, long long z_b,
                                    const float* __restrict__ y, long long y_b, const float* __restrict__ g,
                                    const int* __restrict__ zi, const int* __restrict__ si, const int* __restrict__ ti,
-                                   int n_mod, long long total, long long yt_plane) {
+                                   int n_mod, long long total) {
   const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i >= total) return;
   const int c4 = (int)(i % nc4);
@@ -77,12 +77,8 @@ __global__ void acl_tangent_kernel(float* __restrict__ t, long long t_b, long lo
   const float gs = g ? g[b * y_b + rs] : 1.f, gt = g ? g[b * y_b + rt] : 1.f;
   const float es = expf(-s);
   f32x4* tp = reinterpret_cast<f32x4*>(t + b * t_b + (long long)rz * t_r) + c4;
-  f32x4 sd = reinterpret_cast<const f32x4*>(yt + b * yt_b + (long long)rs * yt_r)[c4];
-  f32x4 td = reinterpret_cast<const f32x4*>(yt + b * yt_b + (long long)rt * yt_r)[c4];
-  if (yt_plane) {                                    // the network's raw tangent as TWO partial planes (fused 1x1 epilogue): add them
-    sd += reinterpret_cast<const f32x4*>(yt + yt_plane + b * yt_b + (long long)rs * yt_r)[c4];
-    td += reinterpret_cast<const f32x4*>(yt + yt_plane + b * yt_b + (long long)rt * yt_r)[c4];
-  }
+  const f32x4 sd = reinterpret_cast<const f32x4*>(yt + b * yt_b + (long long)rs * yt_r)[c4];
+  const f32x4 td = reinterpret_cast<const f32x4*>(yt + b * yt_b + (long long)rt * yt_r)[c4];
   const f32x4 v = *tp;
   *tp = es * (v - (zo * gs) * sd) - gt * td;
 }
@@ -390,17 +386,11 @@ int cmf_acl_primal(float* z, long long z_b, const float* y, long long y_b, const
 int cmf_acl_tangent(float* t, long long t_b, long long t_r, const float* yt, long long yt_b, long long yt_r, int nc,
                     const float* z, long long z_b, const float* y, long long y_b, const float* g, const int* zi,
                     const int* si, const int* ti, int n_mod, int B, void* stream) {
-  return cmf_acl_tangent_planes(t, t_b, t_r, yt, yt_b, yt_r, 0, nc, z, z_b, y, y_b, g, zi, si, ti, n_mod, B, stream);
-}
-
-int cmf_acl_tangent_planes(float* t, long long t_b, long long t_r, const float* yt, long long yt_b, long long yt_r, long long yt_plane,
-                           int nc, const float* z, long long z_b, const float* y, long long y_b, const float* g, const int* zi,
-                           const int* si, const int* ti, int n_mod, int B, void* stream) {
   if (!t || !yt || !z || !y || !zi || !si || !ti || n_mod <= 0 || B <= 0 || nc <= 0 || nc % 4) return CMF_EINVAL;
-  if ((t_b | t_r | yt_b | yt_r | yt_plane) % 4 || (uintptr_t)t % 16 || (uintptr_t)yt % 16) return CMF_EINVAL;
+  if ((t_b | t_r | yt_b | yt_r) % 4 || (uintptr_t)t % 16 || (uintptr_t)yt % 16) return CMF_EINVAL;
   const long long total = (long long)B * n_mod * (nc / 4);
   hipLaunchKernelGGL(acl_tangent_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, t, t_b, t_r, yt, yt_b,
-                     yt_r, nc / 4, z, z_b, y, y_b, g, zi, si, ti, n_mod, total, yt_plane);
+                     yt_r, nc / 4, z, z_b, y, y_b, g, zi, si, ti, n_mod, total);
   CMF_LAUNCH_CHECK();
   return 0;
 }

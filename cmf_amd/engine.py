@@ -94,21 +94,17 @@ class KernelConfig:
              as few mask flips as exact fp32 products, profiles/r04_primal_precision_study.txt) at the bf16 MFMA rate;
              "f32" = exact fp32 MFMA (2.8x slower); "bf16x3" = bf16 split (~2^-16: ~15x more mask flips, median per-sample
              log-det / g_ij error 3e-6 / 1.4e-5 instead of 1e-6 / 2e-7 -- kept as an experiment, never the default)."""
-    __slots__ = ("tangent", "primal", "primal_min_items", "fuse_last_1x1")
+    __slots__ = ("tangent", "primal", "primal_min_items")
 
-    def __init__(self, tangent="bf16x3", primal="f16x3", primal_min_items=96, fuse_last_1x1=True):
+    def __init__(self, tangent="bf16x3", primal="f16x3", primal_min_items=96):
         assert tangent in ("bf16x3", "f32") and primal in ("f16x3", "f32", "bf16x3")
         self.tangent, self.primal = tangent, primal
-        #: evaluation: the last hidden tangent conv of a ResNet coupler also applies the network's final 1x1 conv in its epilogue
-        #: (cmf_conv_tangent_bf16x3_fused1x1); False = two launches
-        self.fuse_last_1x1 = bool(fuse_last_1x1)
         #: launches of the fp16 split primal kernel with fewer (tile, sample group) work items than this use the fp32 kernel's
         #: small-grid forms instead (``_resnet_primal_grouped``)
         self.primal_min_items = int(primal_min_items)
 
     def __repr__(self):
-        return (f"KernelConfig(tangent={self.tangent!r}, primal={self.primal!r}, primal_min_items={self.primal_min_items}, "
-                f"fuse_last_1x1={self.fuse_last_1x1})")
+        return f"KernelConfig(tangent={self.tangent!r}, primal={self.primal!r}, primal_min_items={self.primal_min_items})"
 
 
 _DEFAULT_CONFIG = KernelConfig()
@@ -127,8 +123,7 @@ class scope:
     def __init__(self, config=None, **kw):
         cur = cfg()
         self.config = config if config is not None else KernelConfig(
-            **{**{"tangent": cur.tangent, "primal": cur.primal, "primal_min_items": cur.primal_min_items,
-                  "fuse_last_1x1": cur.fuse_last_1x1}, **kw})
+            **{**{"tangent": cur.tangent, "primal": cur.primal, "primal_min_items": cur.primal_min_items}, **kw})
 
     def __enter__(self):
         if not hasattr(_tls, "cfg"):
@@ -197,9 +192,6 @@ class Tangent:
         numel = self.B * self.N * self.nc
         self.data = data if data is not None else torch.empty(numel, dtype=torch.float32, device=device)
         assert self.data.numel() >= numel
-        #: > 0: the tensor is the SUM of two partial planes, ``data[:numel]`` and ``data[plane:plane + numel]`` (what the fused 1x1
-        #: epilogue of the last hidden conv writes: one plane per 32-channel half; ``acl_tangent`` adds them on load)
-        self.plane = 0
 
     @property
     def t_b(self):
@@ -226,10 +218,6 @@ class Tangent:
 
     def to_dense(self, ncols):
         """(B, N, ncols) torch view/copy for tests and the public jvp API."""
-        if self.plane:
-            n = self.B * self.N * self.nc
-            both = Tangent(self.B, self.N, self.nc, self.layout, self.data.device, data=self.data[:n] + self.data[self.plane:self.plane + n])
-            return both.to_dense(ncols)
         if self.layout == "panel":
             return self.data[: self.B * self.N * self.nc].view(self.B, self.N, self.nc)[:, :, :ncols]
         return self.data[: self.B * self.N * self.nc].view(self.N, self.B, self.nc).permute(1, 0, 2)[:, :, :ncols]
@@ -421,36 +409,6 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
                4.0 * px * (cin + cout + (cout if res_t is not None else 0)), launch)
 
 
-def conv_tangent_fused1x1(x_t, x_np, x_ci, x_px, weight, res_t, r_np, r_co, r_px, np_, cin, H, W, nc, fbits, w1x1, last_bits, x_sl, r_sl):
-    """The coupler's LAST hidden tangent conv (3x3, cin -> 64, relu' of its input from the bit mask ``fbits``, residual ``res_t``) fused
-    with the network's final 1x1 conv ``w1x1`` (n, 64, 1, 1) and the relu' of the last primal activation (``last_bits``): returns the raw
-    output tangent (B, n HW, nc) as a two-plane ``Tangent`` (``plane`` set) -- the 64-channel tensor in between is never written."""
-    lib = _lib.load()
-    n_out, HW, dev = int(w1x1.shape[0]), H * W, x_t.device
-    assert w1x1.shape[1] == 64 and w1x1.is_contiguous() and isinstance(fbits, BitMask) and isinstance(last_bits, BitMask)
-    a = ConvTangentArgs()
-    a.x = _p(x_t); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
-    a.f = _p(fbits.data); a.f_np = fbits.np_bytes; a.fmode = F_RELU_BITS
-    a.w = _p(PACKS.get(weight, 9, False, bf16x3=True))
-    a.r = _p(res_t); a.r_np, a.r_co, a.r_px = int(r_np), int(r_co), int(r_px)
-    a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), 64, int(H), int(W), int(nc), 9
-    a.f_group = 1
-    a.x_sl, a.r_sl = int(x_sl), int(r_sl)
-    numel = np_ * n_out * HW * nc
-    yt = Tangent(np_, n_out * HW, nc, "panel", dev, data=torch.empty(2 * numel, dtype=torch.float32, device=dev))
-    yt.plane = numel
-    launch = lambda: _lib.check(lib.cmf_conv_tangent_bf16x3_fused1x1(C.byref(a), _p(w1x1.detach()), n_out, _p(yt.data), numel, n_out * HW * nc,
-                                                                     HW * nc, nc, _p(last_bits.data), last_bits.np_bytes, _stream()),
-                                "cmf_conv_tangent_bf16x3_fused1x1")
-    TIMER = _timer()
-    if TIMER is None:
-        launch()
-    else:
-        px = float(H) * W * nc * np_
-        TIMER.wrap(f"conv_tangent_t9_ci{cin}_co64", 2.0 * cin * 64 * 9 * px + 2.0 * 64 * n_out * px, 4.0 * px * (cin + 64 + n_out), launch)
-    return yt
-
-
 _WGRAD_WS = {}
 
 
@@ -574,10 +532,9 @@ def acl_primal(z, y, maps, decode, lj=None):
 def acl_tangent(T, YT, z, y, g, maps):
     B = z.shape[0]
     z2, y2 = z.view(B, -1), y.view(B, -1)
-    launch = lambda: _lib.check(_lib.load().cmf_acl_tangent_planes(_p(T.data), T.t_b, T.t_r, _p(YT.data), YT.t_b, YT.t_r, int(YT.plane), T.nc,
-                                                                   _p(z2), z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]),
-                                                                   _p(maps["si"]), _p(maps["ti"]), maps["n"], B, _stream()),
-                                "cmf_acl_tangent_planes")
+    launch = lambda: _lib.check(_lib.load().cmf_acl_tangent(_p(T.data), T.t_b, T.t_r, _p(YT.data), YT.t_b, YT.t_r, T.nc, _p(z2),
+                                                            z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]), _p(maps["si"]),
+                                                            _p(maps["ti"]), maps["n"], B, _stream()), "cmf_acl_tangent")
     TIMER = _timer()
     if TIMER is None:
         return launch()
@@ -816,7 +773,6 @@ DERIVED = _DerivedCache()
 #: fused coupling layers for MLP couplers (cmf_mlp_coupler): False = always the per-layer launches (the training path
 #: always uses them: it needs every layer's state)
 FUSED_MLP = True
-
 
 
 def mlp_coupler_supported(net, view, T, n_out):
@@ -1109,12 +1065,6 @@ def net_primal(net, z, view, need_acts=True):
     return h, None, acts
 
 
-class BitsActs(list):
-    """The "bits" form of a coupler's activations (``[a_0 floats] + relu' BitMasks + [a_K floats]``) plus ``last_bits``: the BitMask
-    of the LAST activation too, for the fused last-conv + 1x1 epilogue (the separate 1x1 launch reads the floats)."""
-    last_bits = None
-
-
 class GroupedActs(list):
     """Primal activations kept as (B/16, C, H, W, 16): 16 samples in the 16 column slots of the tangent kernels
     (supported as a factor source through ``f_group``, but slower to read than the standard layout)."""
@@ -1211,9 +1161,7 @@ def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts
         out.grouped = acts
         return y, g, out
     if bits:
-        out = BitsActs([a0] + masks[:-1] + [std_of(acts[-1])])
-        out.last_bits = masks[-1]
-        return y, g, out
+        return y, g, [a0] + masks[:-1] + [std_of(acts[-1])]
     # The tangent pass reads relu' per (channel, pixel) of ONE sample: from the grouped layout every such read is its
     # own 64-byte line (measured: tangent convs 3.1 -> 4.5 ms); regrouping the 17 saved activations costs ~6 ms / elbo.
     return y, g, [a0] + [std_of(t) for t in acts[1:]]
@@ -1260,17 +1208,9 @@ def net_tangent(net, T, view, acts, transpose_packs=False, save=None):
         # relu' source of a hidden conv: float activations, or the bit mask the primal pass wrote (BitMask)
         fk = lambda t: dict(fmode=F_RELU_BITS, f=t.data, f_np=t.np_bytes) if isinstance(t, BitMask) else dict(fmode=F_RELU, f=t, **fs)
         u, h2 = new(hid), new(hid)
-        # the LAST hidden conv fused with the final 1x1 conv (the 64-channel tangent between them is neither written nor re-read):
-        # evaluation only (training keeps every layer's input tangent), split kernel, bit masks from the primal pass for both factors
-        last_bits = getattr(acts, "last_bits", None)
-        fuse = (cfg().fuse_last_1x1 and save is None and last_bits is not None and hid == 64 and cout in (2, 4) and convf.weight.is_contiguous()
-                and cfg().tangent == "bf16x3" and _shape_ok_bf16x3(9, hid, W, False, H, hid) and isinstance(acts[2 * len(blocks) - 1], BitMask))
         for k, blk in enumerate(blocks):
             a_in, c1 = acts[2 * k], acts[2 * k + 1]
             conv_tangent(h.data, 0, *hd, blk.conv1.weight, 9, u.data, *hd, B, hid, hid, H, W, nc, x_sl=hsl, y_sl=hsl, **fk(a_in))
-            if fuse and k == len(blocks) - 1:
-                return conv_tangent_fused1x1(u.data, *hd, blk.conv2.weight, h.data, *hd, B, hid, H, W, nc, c1, convf.weight, last_bits,
-                                             hsl, hsl)
             conv_tangent(u.data, 0, *hd, blk.conv2.weight, 9, h2.data, *hd, B, hid, hid, H, W, nc, res_t=h.data, x_sl=hsl,
                          y_sl=hsl, **fk(c1))
             if save is not None:                              # keep h_k and u_k: no ping-pong reuse

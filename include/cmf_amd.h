@@ -129,15 +129,6 @@ int cmf_pack_weight_bf16x3(const float* w, void* out, int cout, int cin, long lo
  * [cout][cin][tap] = w[ci][co][8 - tap] (channels swapped, taps flipped: cmf_pack_weight's transpose for the split kernel) */
 int cmf_pack_weight_bf16x3_t(const float* w, void* out, int cout, int cin, int transpose, long long* out_bytes, void* stream);
 int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* a, void* stream);
-/* The coupler's LAST hidden tangent conv fused with the network's final 1x1 conv (networks.py:150-161: relu -> conv1x1(64 -> n),
- * tangent rule jvp_layers.py:38-41, :56-64):  yt(np, o, px, :) = sum_ch w1x1[o][ch] [a_K(np, ch, px) > 0] (conv(F x) + r)(np, ch, px, :),
- * o < n_out in {2, 4}.  `a` as for cmf_conv_tangent_bf16x3 with fmode CMF_F_RELU_BITS, cout == 64, no bias / output factor; a->y is
- * ignored -- the 64-channel result is NOT written.  `mask` = the relu' bit mask of a_K (CMF_F_RELU_BITS layout, mask_np bytes per
- * sample).  yt comes back as TWO partial planes (one per 32-channel half): element (half, np, o, px, col) at
- * yt[half*yt_plane + np*yt_np + o*yt_co + px*yt_px + col]; their sum is the 1x1 conv's output (cmf_acl_tangent_planes adds them). */
-int cmf_conv_tangent_bf16x3_fused1x1(const cmf_conv_tangent_args* a, const float* w1x1, int n_out, float* yt, long long yt_plane,
-                                     long long yt_np, long long yt_co, long long yt_px, const void* mask, long long mask_np,
-                                     void* stream);
 
 /* fp16 split-precision variant for the PRIMAL hidden convs of a ResNet coupler (networks.py:50-60 with 16 samples in the column
  * slots): fmode CMF_F_SELF_RELU, taps == 9, cin % 32 == 0, cout % 64 == 0, tiles as cmf_conv_tangent_bf16x3, no output factor.
@@ -247,11 +238,6 @@ int cmf_acl_cross_terms(const float* c, long long c_b, long long c_r, const floa
 int cmf_acl_tangent(float* t, long long t_b, long long t_r, const float* yt, long long yt_b, long long yt_r,
                     int nc, const float* z, long long z_b, const float* y, long long y_b, const float* g,
                     const int* zi, const int* si, const int* ti, int n_mod, int B, void* stream);
-/* the same with the network's raw tangent given as TWO partial planes, yt and yt + yt_plane (elements), which are added on load:
- * what cmf_conv_tangent_bf16x3_fused1x1 writes (yt_plane == 0: one plane, = cmf_acl_tangent).                              */
-int cmf_acl_tangent_planes(float* t, long long t_b, long long t_r, const float* yt, long long yt_b, long long yt_r,
-                           long long yt_plane, int nc, const float* z, long long z_b, const float* y, long long y_b,
-                           const float* g, const int* zi, const int* si, const int* ti, int n_mod, int B, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Index-map moves: squeeze / unsqueeze (reshaping.py:89-114), split padding (split.py:50-52), tail

@@ -309,27 +309,3 @@ def test_batched_primal_weight_gradients_equal_the_single_launches(H, W, groups)
         (F.conv2d(torch.relu(x).double(), w, padding=1) * g.double()).sum().backward()
         assert rel(d1, w.grad) < 5e-5 and rel(d2 - 0.5, w.grad) < 5e-5
         assert rel(d2 - 0.5, d1) < 2e-6                         # the same products, dealt to 48 instead of up to 56 workgroups
-
-
-@pytest.mark.parametrize("name,rep", [("c3_mnist_full", 8), ("c5_cifar_full", 8)])
-def test_last_hidden_conv_fused_with_the_1x1_equals_the_two_launches(name, rep):
-    """``cmf_conv_tangent_bf16x3_fused1x1`` -- the coupler's last hidden tangent conv contracts its own output
-    tile with the final 1x1 conv's weights (relu' of the last primal activation from its bit mask) in the epilogue, two partial
-    planes (one per 32-channel half) added by the coupling update.  Full-size MNIST (2 -> 2 / 4 outputs, 2 x 14 tiles) and CIFAR
-    (4 x 8 tiles) models: Jacobian, Gram matrix, log-det equal the unfused path's to rounding, and the reference's vectors."""
-    from cmf_amd import engine as E
-    g, meta, cfg, dens = build(name)
-    head = find_head(dens)
-    x = (g["x"] + g["noise"]).repeat(rep, 1, 1, 1).cuda()                 # 16 samples: the grouped primal path (bit masks) runs
-    out, grams, names = {}, {}, {}
-    for fuse in (True, False):
-        head.kernels = E.KernelConfig(fuse_last_1x1=fuse)
-        with E.timing(lambda n: True) as timer, torch.no_grad():
-            out[fuse] = inner(dens, True).elbo(x, add_offdiagonal_metric_reg=(name != "c5_cifar_full"))["elbo"].clone()
-        grams[fuse] = head.last_gram
-        names[fuse] = {k: v[0] for k, v in timer.by_name().items()}
-    n1x1 = sum(v for k, v in names[False].items() if k.startswith("conv_tangent_t1_ci64"))
-    assert n1x1 == 10 and not any(k.startswith("conv_tangent_t1_ci64") for k in names[True])    # the 1x1 launches are gone
-    assert rel(grams[True].jtj, grams[False].jtj) < 2e-6 and rel(grams[True].logdet, grams[False].logdet) < 1e-6
-    assert rel(out[True], out[False]) < 1e-6
-    assert rel(grams[True].logdet[0:2].view(-1, 1), g["logdet"]) < 1e-4 and rel(grams[True].jtj[0:2], g["jtj"]) < 1e-4
