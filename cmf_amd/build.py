@@ -35,7 +35,7 @@ def _digest(paths):
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
-            h.update(p.encode() + b"\0" + f.read())
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())      # path-independent: the tree travels to the GPU box
     return h.hexdigest()
 
 
