@@ -89,6 +89,7 @@ SIGNATURES = {
     "cmf_accumulate": (_i, [_fp, _fp, _ll, _fp]),
     "cmf_relu_bits": (_i, [_fp, _fp, _i, _i, _i, _fp]),
     "cmf_channel_sum": (_i, [_fp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _fp, _fp]),
+    "cmf_channel_sum_batched": (_i, [C.POINTER(_fp), C.POINTER(_fp), _i, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _fp]),
     "cmf_grad_sqnorm": (_i, [_fp, _ll, _fp, _fp, _fp]),
     "cmf_optimizer_step": (_i, [_i, _fp, _fp, _fp, _fp, _ll, _d, _d, _d, _d, _d, _i, _fp, _f, _fp]),
     "cmf_gram_backward_matrix": (_i, [_fp, _ll, _ll, _i, _i, _i, _i, _fp, _fp, _ll, _ll, _fp]),

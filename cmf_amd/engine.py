@@ -621,6 +621,15 @@ def channel_sum(t, t_np, t_c, t_px, np_, Cc, npx, nc, out, t_sl=16):
                                            _p(out), _stream()), "cmf_channel_sum")
 
 
+def channel_sum_batched(ts, t_np, t_c, t_px, np_, Cc, npx, nc, outs, t_sl=16):
+    """``channel_sum`` for up to 16 tensors of one shape in one launch (lists of tensors and of the bias-gradient vectors)."""
+    n = len(ts)
+    assert n == len(outs) and 1 <= n <= _lib.WGRAD_MAX_BATCH
+    arr = lambda xs: (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    _lib.check(_lib.load().cmf_channel_sum_batched(arr(ts), arr(outs), n, int(t_np), int(t_c), int(t_px), int(t_sl), int(np_), int(Cc), int(npx),
+                                                   int(nc), _stream()), "cmf_channel_sum_batched")
+
+
 class GramResult:
     __slots__ = ("jtj", "logdet", "l1_off", "l1_diag", "info", "fail", "attempts")
 
@@ -1413,7 +1422,7 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
     # 43 us per C3 step at 64 samples, 12 ms per C5 step at 32)
     gs = hid * HW * 16                                  # group stride = slice stride
     batch_wgrads = pair and (G // 2) * H < 256 and hid == 64
-    pending = []
+    pending, pending_bias = [], []
 
     def flush_wgrads():
         for i in range(0, len(pending), _lib.WGRAD_MAX_BATCH):
@@ -1421,6 +1430,16 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
             conv_tangent_wgrad_batched([p[0] for p in part], [p[1] for p in part], [p[2] for p in part], 2 * gs, HW * 16, 16,
                                        2 * gs, HW * 16, 16, G // 2, hid, hid, H, W, 32, fmode=F_SELF_RELU, x_sl=gs, y_sl=gs)
         pending.clear()
+        for i in range(0, len(pending_bias), _lib.WGRAD_MAX_BATCH):       # the hidden convs' bias gradients: one launch too
+            part = pending_bias[i:i + _lib.WGRAD_MAX_BATCH]
+            channel_sum_batched([p[0] for p in part], *pn(hid), G, hid, HW, 16, [p[1] for p in part])
+        pending_bias.clear()
+
+    def hidden_bias_grad(gy_g, bias):
+        if batch_wgrads:
+            pending_bias.append((gy_g, _grad_of(grads, bias)))
+        else:
+            channel_sum(gy_g, *pn(hid), G, hid, HW, 16, _grad_of(grads, bias))
 
     def hidden_wgrad(x_g, gy_g, weight):               # 3x3, hid -> hid, the input's own relu
         if batch_wgrads:
@@ -1447,11 +1466,11 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
         a_in, c1 = gact(2 * k), gact(2 * k + 1)
         # a' = a + conv2(relu(c1)) + b2,  c1 = conv1(relu(a)) + b1
         hidden_wgrad(c1, da, blk.conv2.weight)
-        channel_sum(da, *pn(hid), G, hid, HW, 16, _grad_of(grads, blk.conv2.bias))
+        hidden_bias_grad(da, blk.conv2.bias)
         dc1 = new(hid)
         conv_tangent(da, 0, *pn(hid), blk.conv2.weight, 9, dc1, *pn(hid), G, hid, hid, H, W, 16, **self_fo(c1), **tr)
         hidden_wgrad(a_in, dc1, blk.conv1.weight)
-        channel_sum(dc1, *pn(hid), G, hid, HW, 16, _grad_of(grads, blk.conv1.bias))
+        hidden_bias_grad(dc1, blk.conv1.bias)
         da2 = new(hid)
         conv_tangent(dc1, 0, *pn(hid), blk.conv1.weight, 9, da2, *pn(hid), G, hid, hid, H, W, 16, res_t=da, **self_fo(a_in), **tr)
         da = da2

@@ -422,6 +422,9 @@ int cmf_relu_bits(const float* act, void* out, int B, int C, int HW, void* strea
  * (col/16)*t_sl + col%16, t_sl = 0 meaning 16): the bias gradient of nn.Conv2d / nn.Linear.                        */
 int cmf_channel_sum(const float* t, long long t_np, long long t_c, long long t_px, long long t_sl, int np, int C,
                     int npx, int nc, float* out, void* stream);
+/* n <= CMF_WGRAD_MAX_BATCH tensors of ONE shape in one launch (t, out: HOST arrays of device pointers): out[k][c] += the sums of t[k]. */
+int cmf_channel_sum_batched(const float* const* t, float* const* out, int n, long long t_np, long long t_c, long long t_px,
+                            long long t_sl, int np, int C, int npx, int nc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimiser step over one flat fp32 buffer: replaces the per-parameter loop of
