@@ -309,3 +309,21 @@ def test_batched_primal_weight_gradients_equal_the_single_launches(H, W, groups)
         (F.conv2d(torch.relu(x).double(), w, padding=1) * g.double()).sum().backward()
         assert rel(d1, w.grad) < 5e-5 and rel(d2 - 0.5, w.grad) < 5e-5
         assert rel(d2 - 0.5, d1) < 2e-6                         # the same products, dealt to 48 instead of up to 56 workgroups
+
+
+def test_batched_channel_sums_equal_the_single_launches():
+    """cmf_channel_sum_batched: the bias gradients of several cotangent tensors of one shape (16 samples in the column slots) in ONE
+    launch, accumulated INTO their outputs like cmf_channel_sum."""
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(2)
+    G, C, HW, n = 3, 64, 14 * 14, 5
+    ts = [torch.randn(G * C * HW * 16, generator=gen).cuda() for _ in range(n)]
+    pn = (C * HW * 16, HW * 16, 16)
+    single = [torch.full((C,), 0.25, device="cuda") for _ in range(n)]
+    batched = [torch.full((C,), 0.25, device="cuda") for _ in range(n)]
+    for t, o in zip(ts, single):
+        E.channel_sum(t, *pn, G, C, HW, 16, o)
+    E.channel_sum_batched(ts, *pn, G, C, HW, 16, batched)
+    for t, a, b in zip(ts, single, batched):
+        assert torch.equal(a, b)
+        assert rel(a - 0.25, t.view(G, C, HW * 16).double().sum((0, 2))) < 1e-5
