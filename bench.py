@@ -258,7 +258,8 @@ def cpu_model():
 
 #: libcmf_amd symbol -> stage of the per-stage breakdown (calls inside FlowProgram.encode all count as "encode")
 STAGE_OF = {"cmf_conv_tangent_bf16x3": "tangent_hidden", "cmf_conv_tangent": "tangent_first_last",
-            "cmf_conv_tangent_f16x3": "primal", "cmf_conv_primal": "primal", "cmf_primal_regroup": "primal", "cmf_absmax": "primal",
+            "cmf_conv_tangent_f16x3": "primal", "cmf_conv_tangent:primal": "primal", "cmf_conv_tangent_bf16x3:primal": "primal",
+            "cmf_conv_primal": "primal", "cmf_primal_regroup": "primal", "cmf_absmax": "primal",
             "cmf_acl_tangent": "acl", "cmf_acl_primal": "acl", "cmf_gram_cholesky": "gram_cholesky", "cmf_cholesky_retry": "gram_cholesky",
             "cmf_mlp_coupler": "mlp_coupler"}
 STAGES = ("encode", "primal", "tangent_hidden", "tangent_first_last", "acl", "gram_cholesky", "other", "host_gap")
@@ -324,7 +325,37 @@ def kernel_source_sha16(precision):
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def train_leg(steps, warmup, config, density, x, B, rank, world, device, off=True):
+def grad_reduce_leg(n, rank, world, device, iters=20, warmup=3):
+    """N > 1 only (gradient reduction shaped for the point-to-point xGMI mesh): the flat gradient bucket of the C3 model
+    (``n`` floats + the sample-count word) summed over the ranks as ONE all-reduce and as reduce-scatter + all-gather
+    (cmf_amd.distributed.sum_flat), ``iters`` calls each between barrier + synchronize brackets, max over ranks.  The training
+    legs of the line use the faster shape."""
+    import torch
+    import torch.distributed as dist
+    from cmf_amd.distributed import sum_flat, rs_ag_scratch, REDUCE_SHAPES
+    bucket = torch.zeros(n + 4, dtype=torch.float32, device=device)
+    scratch = torch.empty(rs_ag_scratch(n + 4), dtype=torch.float32, device=device)
+    us = {}
+    for shape in REDUCE_SHAPES:
+        for _ in range(warmup):
+            sum_flat(bucket, shape, scratch)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            sum_flat(bucket, shape, scratch)
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        us[shape] = 1e6 * float(dt.item()) / iters
+    best = min(REDUCE_SHAPES, key=lambda k: us[k])             # the same on every rank: the times are the max over ranks
+    return {"unit": "us per reduction", "bytes": 4 * (n + 4), "iters": iters, **{k: us[k] for k in REDUCE_SHAPES}, "used": best,
+            "bus_gbs": {k: 2.0 * (world - 1) / world * 4 * (n + 4) / (us[k] * 1e-6) / 1e9 for k in REDUCE_SHAPES},
+            "note": "bus_gbs = 2 (N-1)/N x bytes / time, the ring-equivalent bus bandwidth; one collective after the backward pass, "
+                    "not overlapped with it (a 24 MB bucket against a 185 ms step)"}
+
+
+def train_leg(steps, warmup, config, density, x, B, rank, world, device, off=True, reduce_shape="all_reduce"):
     """Secondary metric: training samples / s (one process per GPU, flat gradient all-reduce over RCCL, fused Adam).  C3: the
     Cholesky objective with the off-diagonal metric term; C5: train mode selects the Hutchinson + CG surrogate
     (non_square.py:131-138), whose backward runs through the 2 S probe directions.  Returns the result object (rank 0) or None."""
@@ -332,7 +363,7 @@ def train_leg(steps, warmup, config, density, x, B, rank, world, device, off=Tru
     import torch.distributed as dist
     from cmf_amd.optim import FlatOptimizer
     density.train()
-    opt = FlatOptimizer(density.parameters(), opt="adam", lr=1e-4)
+    opt = FlatOptimizer(density.parameters(), opt="adam", lr=1e-4, reduce_shape=reduce_shape)
     kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=off, likelihood_wt=1., metric_wt=1.)
 
     def step():
@@ -375,7 +406,7 @@ def train_leg(steps, warmup, config, density, x, B, rank, world, device, off=Tru
         "config": {"workload": ("C3 / C4 model, one optimiser step per batch, g_ij off-diagonal objective" if config == "c3" else
                                 CONFIGS[config][4] + ", one optimiser step per batch, train-mode objective (Hutchinson S=4 + CG)"),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "loss": float(loss),
-                   "peak_memory_gib": peak}}
+                   "peak_memory_gib": peak, "gradient_reduction": reduce_shape if world > 1 else None}}
 
 
 def dominant(rows):
@@ -612,6 +643,13 @@ def run_rank(args):
     stages = None
     if rank == 0 and not args.train and not args.no_kernel_timer and not args.hutchinson:
         stages = stages_leg(wl, 1e3 * dt / args.steps)
+    if default_run and world > 1:
+        # the gradient bucket's two reduction shapes, then the reference's actual multi-GPU workload (DataParallel TRAINING, 64
+        # samples per GPU = configs[3]'s shard) with the faster one.  Last on this model: the optimiser steps change its weights
+        n_par = sum((p.numel() + 3) // 4 * 4 for p in inner.parameters() if p.requires_grad)
+        legs["grad_reduce"] = grad_reduce_leg(n_par, rank, world, device)
+        x64 = synth_batch(dataset, shape, 64, rank, device)
+        legs["train"] = train_leg(args.leg_steps, 1, "c3", inner, x64, 64, rank, world, device, off, legs["grad_reduce"]["used"])
     f32 = None
     if default_run and world == 1:
         if not args.no_f32_exact:

@@ -137,7 +137,8 @@ class _Traced:
             e0.record()
             rc = fn(*args)
             e1.record()
-            self._sink.append((name, getattr(_tls, "phase", None), e0, e1))
+            role = getattr(_tls, "role", None)
+            self._sink.append((name + ":" + role if role else name, getattr(_tls, "phase", None), e0, e1))
             return rc
         return call
 
@@ -167,6 +168,22 @@ class phase:
 
     def __exit__(self, *exc):
         _tls.phase = self.prev
+        return False
+
+
+class role:
+    """``with role("primal"):`` -- calls traced inside are recorded as "<symbol>:primal" (one kernel serving two stages: the fp32
+    tangent conv also runs the sample-grouped primal convs of small shards)."""
+
+    def __init__(self, label):
+        self.label = label
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "role", None)
+        _tls.role = self.label
+
+    def __exit__(self, *exc):
+        _tls.role = self.prev
         return False
 
 

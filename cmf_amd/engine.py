@@ -399,6 +399,12 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     fn, what = ((lib.cmf_conv_tangent_f16x3, "cmf_conv_tangent_f16x3") if f16 else
                 (lib.cmf_conv_tangent_bf16x3, "cmf_conv_tangent_bf16x3") if split else (lib.cmf_conv_tangent, "cmf_conv_tangent"))
     launch = lambda: _lib.check(fn(C.byref(a), _stream()), what)
+    if fmode == F_SELF_RELU and not f16 and getattr(_lib._tls, "sink", None) is not None:
+        run = launch
+
+        def launch():                                       # traced: a primal launch of a tangent kernel (bench.py's stages)
+            with _lib.role("primal"):
+                run()
     TIMER = _timer()
     if TIMER is None:
         return launch()

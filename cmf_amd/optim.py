@@ -37,7 +37,8 @@ class FlatOptimizer(torch.optim.Optimizer):
     """A ``torch.optim.Optimizer`` (so ``torch.optim.lr_scheduler.*`` -- the reference's CosineAnnealingLR / LambdaLR,
     experiment.py:536-552 -- drive it through ``param_groups[0]["lr"]``) whose step is the fused HIP kernel."""
 
-    def __init__(self, params, opt="adam", lr=1e-3, weight_decay=0., betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None):
+    def __init__(self, params, opt="adam", lr=1e-3, weight_decay=0., betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None,
+                 reduce_shape="all_reduce"):
         if opt not in KINDS:
             raise AssertionError(f"Invalid optimiser type {opt}")       # experiment.py:522
         params = [p for p in params if p.requires_grad]
@@ -53,6 +54,9 @@ class FlatOptimizer(torch.optim.Optimizer):
                 raise ValueError("all parameters must be float32 on one device")
         self.opt = opt
         self.max_grad_norm = max_grad_norm
+        #: distributed.REDUCE_SHAPES: how ``allreduce_flat`` sums the bucket over the ranks
+        self.reduce_shape = reduce_shape
+        self._scratch = None
         self.t = 0
         # 16-byte aligned slots: every tensor starts on a multiple of 4 floats, the gaps stay zero forever (g = 0 there)
         self.offsets, n = [], 0
@@ -113,16 +117,23 @@ class FlatOptimizer(torch.optim.Optimizer):
         sum_r n_r g_r / sum_r n_r -- what the reference's DataParallel gather + ``.mean()`` differentiates
         (wrapper.py:52-54, non_square_helpers.py:120) -- also when the shards are unequal.  Without it: plain mean over ranks."""
         import torch.distributed as dist
+        from .distributed import sum_flat, rs_ag_scratch
         self._check_views()                                   # autograd may have replaced p.grad: fold it back BEFORE reducing
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            if n_local is not None and average:
+            weighted = n_local is not None and average
+            bucket = self._bucket if weighted else self.grad
+            if self.reduce_shape == "rs_ag":
+                need = rs_ag_scratch(bucket.numel())
+                if self._scratch is None or self._scratch.numel() < need:
+                    self._scratch = torch.empty(need, dtype=torch.float32, device=bucket.device)
+            if weighted:
                 self.grad.mul_(float(n_local))
                 self._bucket[self.n:].zero_()
                 self._bucket[self.n] = float(n_local)
-                dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
+                sum_flat(bucket, self.reduce_shape, self._scratch)
                 self.grad.div_(self._bucket[self.n])
             else:
-                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+                sum_flat(bucket, self.reduce_shape, self._scratch)
                 if average:
                     self.grad.mul_(1.0 / dist.get_world_size())
 

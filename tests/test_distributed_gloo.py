@@ -163,3 +163,49 @@ def test_weighted_gradient_mean_equals_the_global_batch_mean():
     for r in range(2):
         for got, p in zip(res[r][2], net.parameters()):
             assert torch.allclose(torch.from_numpy(got), p.grad, rtol=1e-5, atol=1e-7)
+
+
+def _sum_flat_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cmf_amd.distributed import sum_flat, rs_ag_scratch
+        out = {}
+        for n in (12, 13, 1, 1000003):                  # a multiple of the world size, ragged, shorter than the world, a large odd one
+            g = torch.Generator().manual_seed(100 * n + rank)
+            mine = torch.randn(n, generator=g)
+            a = sum_flat(mine.clone(), "all_reduce")
+            b = sum_flat(mine.clone(), "rs_ag")
+            scratch = torch.full((rs_ag_scratch(n) + 5,), float("nan"))       # caller-owned scratch, stale contents
+            c = sum_flat(mine.clone(), "rs_ag", scratch)
+            out[n] = (a.numpy().copy(), b.numpy().copy(), c.numpy().copy())
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduce_scatter_all_gather_sums_like_all_reduce(world):
+    """``sum_flat``'s two shapes (one all-reduce; reduce-scatter + all-gather over equal, zero-padded slices) give every rank the
+    same sums -- the float64 sum of the ranks' buckets to fp32 rounding, and bit-identical to each other at two ranks (one
+    addition per element either way)."""
+    port = 29571 + world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sum_flat_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for n in (12, 13, 1, 1000003):
+        want = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 * n + r)).double() for r in range(world))
+        for r in range(world):
+            a, b, c = (torch.from_numpy(t) for t in res[r][n])
+            for got in (a, b, c):
+                assert got.shape == (n,) and torch.allclose(got.double(), want, rtol=0, atol=4e-7 * world)
+            assert torch.equal(b, c) and torch.equal(b, torch.from_numpy(res[0][n][1]))       # every rank holds the same bytes
+            if world == 2:
+                assert torch.equal(a, b)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, reduce_shape):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -34,17 +34,17 @@ def _worker(rank, world, port, q):
             shard = x
         else:
             shard = x[rank * 4:(rank + 1) * 4]
-        opt = FlatOptimizer(dens.parameters(), opt="adam", lr=1e-3)
+        opt = FlatOptimizer(dens.parameters(), opt="adam", lr=1e-3, reduce_shape=reduce_shape)
         out = train_batch(dens, shard.clone(), 10_000, train_metrics, [opt])
         q.put((rank, float(out["metrics"]["loss"].detach()), opt.grad.cpu().numpy().copy(), opt.flat.cpu().numpy().copy()))
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, port):
+def _run(world, port, reduce_shape="all_reduce"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, reduce_shape)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=150) for _ in range(world)), key=lambda t: t[0])
@@ -64,3 +64,10 @@ def test_two_rank_training_step_equals_the_full_batch_step():
         assert np.abs(two[rank][2] - g1).max() <= 1e-5 * np.abs(g1).max()
         assert np.abs(two[rank][3] - p1).max() <= 1e-6 * np.abs(p1).max() + 1e-7
     assert abs(0.5 * (two[0][1] + two[1][1]) - one[0][1]) <= 1e-5 * abs(one[0][1])
+    # the bucket summed as reduce-scatter + all-gather (FlatOptimizer.reduce_shape): at two ranks the same single addition per element
+    # -- the reduced gradients may differ from the all-reduce's only through the backward's own run-to-run atomics
+    rs = _run(2, port + 2, "rs_ag")
+    for rank in range(2):
+        assert np.array_equal(rs[rank][2], rs[0][2]) and np.array_equal(rs[rank][3], rs[0][3])      # the ranks stay replicas
+        assert np.abs(rs[rank][2] - g1).max() <= 1e-5 * np.abs(g1).max()
+        assert np.abs(rs[rank][3] - p1).max() <= 1e-6 * np.abs(p1).max() + 1e-7

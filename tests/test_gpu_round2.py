@@ -315,7 +315,7 @@ def test_bench_launches_two_ranks_from_a_bare_shell():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
     assert line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
     assert line["value"] > 0 and "REHEARSAL" in line["data"]
-    assert "cpu_baseline" not in line and "f32_exact" not in line and "train" not in line
+    assert "cpu_baseline" not in line and "f32_exact" not in line and "c5_train" not in line
     # round 3: the N > 1 line also carries BASELINE configs[3] (the global batch of 512 sharded over the ranks) and configs[4]
     # (CIFAR d = 128, 32 samples per GPU), timed in the same process group
     s3, c5 = line["strong_c3"], line["c5"]
@@ -326,6 +326,12 @@ def test_bench_launches_two_ranks_from_a_bare_shell():
         assert abs(leg["value"] - leg["global_batch"] * leg["steps"] / (leg["ms_per_step"] * 1e-3 * leg["steps"])) / leg["value"] < 1e-6
     assert s3["scaling"] == "strong" and s3["per_gpu_batch"] == 256 and s3["global_batch"] == 512 and "MNIST" in s3["metric"]
     assert c5["scaling"] == "weak" and c5["per_gpu_batch"] == 32 and c5["global_batch"] == 64 and "CIFAR" in c5["metric"]
+    # round 4: the gradient bucket summed in both shapes (all-reduce; reduce-scatter + all-gather), and the data-parallel TRAINING
+    # step -- what the reference's DataParallel is for -- on the faster one
+    gr, tr = line["grad_reduce"], line["train"]
+    assert gr["used"] in ("all_reduce", "rs_ag") and gr["all_reduce"] > 0 and gr["rs_ag"] > 0 and gr["bytes"] > 20e6
+    assert gr["used"] == min(("all_reduce", "rs_ag"), key=lambda k: gr[k])
+    assert tr["n_gpus"] == 2 and tr["config"]["global_batch"] == 128 and tr["config"]["gradient_reduction"] == gr["used"] and tr["value"] > 0
 
 
 @pytest.mark.parametrize("config", ["c1", "c2b"])
