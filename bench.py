@@ -451,7 +451,7 @@ def set_kernels(density, tangent=None, primal=None):
     from cmf_amd import engine as E
     for m in density.modules():
         if isinstance(getattr(m, "kernels", None), E.KernelConfig):
-            m.kernels = E.KernelConfig(tangent or m.kernels.tangent, primal or m.kernels.primal, m.kernels.primal_min_items)
+            m.kernels = E.KernelConfig(tangent or m.kernels.tangent, primal or m.kernels.primal)
 
 
 class Workload:

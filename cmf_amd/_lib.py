@@ -64,6 +64,7 @@ SIGNATURES = {
     "cmf_conv_tangent_bf16x3": (_i, [C.POINTER(ConvTangentArgs), _fp]),
     "cmf_pack_weight_f16x3": (_i, [_fp, _fp, _i, _i, _i, C.POINTER(_ll), _fp]),
     "cmf_conv_tangent_f16x3": (_i, [C.POINTER(ConvTangentArgs), _fp]),
+    "cmf_conv_tangent_f16x3_item": (_i, [C.POINTER(ConvTangentArgs), _i, _fp]),
     "cmf_absmax": (_i, [_fp, _ll, _fp, _fp]),
     "cmf_conv_tangent_wgrad_ws": (_ll, [C.POINTER(ConvTangentArgs)]),
     "cmf_conv_tangent_wgrad": (_i, [C.POINTER(ConvTangentArgs), _fp, _fp, _fp, _ll, _fp]),

@@ -133,7 +133,12 @@ __device__ __forceinline__ int xslot(int col, int pix) { return (((col & 3) << 2
 template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false>
 __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
                                                                        int nslices, int ncog, int total) {
-  static_assert(!F16 || (MODE == 2 && COT == 4), "the fp16 variant is the primal pass: SELF mode, 64-channel groups");
+  static_assert(!F16 || (MODE == 2 && (COT == 4 || COT == 2)), "the fp16 variant is the primal pass: SELF mode");
+  // HALF (F16 with COT == 2): an item is 32 output channels of a 64-channel group, `cog` counts HALF groups -- twice the items for
+  // launches that would leave most of the chip idle (a 32-sample CIFAR shard: 64 items of 64 channels for 256 CUs).  The weight
+  // pack is the 64-channel one: a half reads two of the slab's four channel tiles.
+  constexpr bool HALF = F16 && COT == 2;
+  constexpr int COG = HALF ? 32 : 64;                            // output channels per item
   static_assert(!FRES || F16, "residual-in-the-epilogue is the fp16 variant's");
   // MODE: 0 = general factor formula, 1 = relu factor (2 instead of 6 VALU per channel in the loader), 2 = SELF (the
   // input's own relu, no factor stream).  Compile-time: every loader VALU instruction delays the MFMA wave it shares
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     int xs = ex == 0 ? 0 : 14 - (ex - 126);
     xs = xs < -60 ? -60 : xs > 40 ? 40 : xs;
     const float* trailer = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.w) +
-                                                          (long long)ncog * nchunks * BCfg<COT, PXW>::W_CHUNK_BYTES);
+                                                          (long long)(HALF ? ncog / 2 : ncog) * nchunks * BCfg<COT, PXW>::W_CHUNK_BYTES);
     const float wscale = trailer[0], winv = trailer[1];
     xscale = pow2i(xs);
     oscale = winv * pow2i(-xs);
@@ -284,10 +289,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     // ahead, right after the previous slab was written to LDS (three sets cost 48 more VGPRs and spilled).
     u32x4 wreg[C::NWIT];
     int wcur_item = 0, wcur_ch = 0;
+    [[maybe_unused]] int whalf = 0;                                // HALF: byte offset of the item's two channel tiles inside a K-step
     auto wset_item = [&](int item) {
       int tile, slice, cog, np;
       decode(item, tile, slice, cog, np);
-      wrs = make_rsrc(reinterpret_cast<const unsigned char*>(a.w) + (long long)cog * nchunks * C::W_CHUNK_BYTES);
+      wrs = make_rsrc(reinterpret_cast<const unsigned char*>(a.w) + (long long)(HALF ? cog >> 1 : cog) * nchunks * C::W_CHUNK_BYTES);
+      if constexpr (HALF) whalf = __builtin_amdgcn_readfirstlane((cog & 1) * 2 * 64 * 16);
     };
     // `s_nop 4` opens every load statement: descriptor / soffset SGPRs may have just been written by SALU code.
     auto prefetch_w = [&]() {
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
       for (int it = 0; it < C::NWIT; ++it) {
         const int vo = woff[COT == 4 ? 0 : it % NWOFF];
-        const int so = COT == 4 ? wco + it * 4096 : wco;
+        const int so = COT == 4 ? wco + it * 4096 : HALF ? wco + whalf : wco;
         if (COT == 4 && it % 3 == 2) {
           asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(wreg[it]) : "v"(vo), "s"(wrs2), "s"(so) : "memory");
           continue;
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // wraps every access in a waterfall loop
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   auto y_rsrc = [&](int np, int slice, int cog) {
-    const unsigned long long u = reinterpret_cast<unsigned long long>(a.y + (long long)np * a.y_np + (long long)slice * (a.y_sl ? a.y_sl : 16) + (long long)cog * 64 * y_co);
+    const unsigned long long u = reinterpret_cast<unsigned long long>(a.y + (long long)np * a.y_np + (long long)slice * (a.y_sl ? a.y_sl : 16) + (long long)cog * COG * y_co);
     const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
     const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
     // num_records 0x7fffff00: every real offset (a lane's channel / column term, far below 2^31) passes the range check, the
@@ -599,11 +606,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   };
   constexpr int Y_DROP = 0x7ffffff0;
   // F16: relu' bit mask of the stored values (CMF_F_RELU_BITS layout of the next conv): per pixel ONE dword per sample = the 32
-  // channel bits of this wave's channel half, stored by lane s < 16 for sample slice*16 + s; the other lanes (and
-  // every lane when mask_out is NULL: zero records) store past the descriptor's range -- dropped, still counted by vmcnt
+  // channel bits of this wave's channel half (HALF: one 16-bit word = its 16 channels), stored by lane s < 16 for sample
+  // slice*16 + s; the other lanes (and every lane when mask_out is NULL: zero records) store past the descriptor's range --
+  // dropped, still counted by vmcnt
   [[maybe_unused]] auto m_rsrc = [&](int np, int slice, int cog) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(a.mask_out ? a.mask_out : (void*)a.y) +
-                                 (unsigned long long)((long long)np * a.nc + slice * 16) * a.mask_np + (unsigned)(cog * 8 + cohalf * 4);
+                                 (unsigned long long)((long long)np * a.nc + slice * 16) * a.mask_np + (unsigned)(cog * (COG / 8) + cohalf * (COG / 16));
     const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
     const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0,
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   const int mvoff = lane < 16 ? lane * (int)a.mask_np : Y_DROP;
   float ymax = 0.f;                                                // F16: running max of the stored values (-> *amax_out)
   auto r_rsrc = [&](int np, int slice, int cog, bool on) {         // words, for the inline-asm loads
-    const float* base = a.r ? a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) + (long long)cog * 64 * r_co : a.y;
+    const float* base = a.r ? a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) + (long long)cog * COG * r_co : a.y;
     const unsigned long long u = reinterpret_cast<unsigned long long>(base);
     i32x4 d;
     d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
@@ -631,6 +639,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // among the hand-counted ones; a NULL bias is a zero-record descriptor (reads 0).  (A per-store
   // `a.bias ? a.bias[..] : 0` once put a dependent load + s_waitcnt vmcnt(0) in front of EVERY store: ~28k cycles/item.)
   float bias[CW];
+  [[maybe_unused]] float bias_h1 = 0.f;                            // HALF: the constant of this lane's channel in the odd halves
   {
     const unsigned long long u = reinterpret_cast<unsigned long long>(a.bias ? a.bias : a.y);
     i32x4 d;
@@ -643,6 +652,10 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     for (int c = 0; c < CW; ++c) {
       const int so = 4 * c * 16;
       asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(bias[c]) : "v"(bvo), "s"(d), "s"(so) : "memory");
+    }
+    if constexpr (HALF) {
+      const int so = 4 * 32;
+      asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(bias_h1) : "v"(bvo), "s"(d), "s"(so) : "memory");
     }
   }
   auto cur_yrs = y_rsrc(np_, slice_, cog_);
@@ -707,7 +720,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         if constexpr (inplace) vo = on ? yvoff : Y_DROP;
         else v = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if constexpr (F16) v = v * oscale + bias[c];                 // undo the operand scales (exact), then the bias
+      if constexpr (HALF) v = v * oscale + ((it.cog & 1) ? bias_h1 : bias[c]);
+      else if constexpr (F16) v = v * oscale + bias[c];            // undo the operand scales (exact), then the bias
       else v += bias[c];                                           // per-channel constant (primal bias)
       if constexpr (FRES) v += c == 0 ? radd0 : radd1;             // the residual, once, after the products
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, v), cur_yrs, vo,
@@ -719,7 +733,27 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(ymax) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
       }
     }
-    if constexpr (F16) {
+    if constexpr (HALF) {
+      // one channel tile: the ballot's 16-bit quarter kq of register r IS sample 4 kq + r's word
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        unsigned alo, ahi, d;
+        asm volatile(
+            "v_cmp_lt_f32 vcc, 0, %4\n\t"
+            "s_mov_b32 %1, vcc_lo\n\t"
+            "s_mov_b32 %2, vcc_hi\n\t"
+            "v_writelane_b32 %0, %1, %5\n\t"
+            "s_lshr_b32 %3, %1, 16\n\t"
+            "v_writelane_b32 %0, %3, %6\n\t"
+            "v_writelane_b32 %0, %2, %7\n\t"
+            "s_lshr_b32 %3, %2, 16\n\t"
+            "v_writelane_b32 %0, %3, %8"
+            : "+v"(mbits), "=&s"(alo), "=&s"(ahi), "=&s"(d)
+            : "v"(vst[0][r]), "n"(r), "n"(4 + r), "n"(8 + r), "n"(12 + r)
+            : "vcc", "scc");
+      }
+      __builtin_amdgcn_raw_buffer_store_b16((unsigned short)mbits, cur_mrs, mvoff, (it.pix0 + (p / C::TW) * a.W + p % C::TW) * (a.cout / 8), 0);
+    } else if constexpr (F16) {
       // sign bits -> lanes: the ballot of register r of channel tile c holds, in its 16-bit quarter kq, the 16 channel bits of
       // sample 4 kq + r.  SALU packs the quarters of the two tiles into one dword per sample (32 channels), v_writelane parks it
       // in lane 4 kq + r: 8 v_cmp + 16 v_writelane + 24 SALU per pixel, one VGPR, no per-lane selects
@@ -906,7 +940,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   // item 0: a block of loads, not the tail pattern (+ the bias)
   static_assert(CW == 2 || CW == 1, "operand list below");
   if constexpr (CW == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1])::"memory");
-  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0])::"memory");
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias_h1)::"memory");
   __syncthreads();                                                 // stage 0 ready
   for (int item = 0; item < n_items; ++item) {
     const bool has_next = item + 1 < n_items;
@@ -954,7 +988,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         decode(item, tile, slice, cog, np);
       }
       const unsigned long long ru = reinterpret_cast<unsigned long long>(a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) +
-                                                                         (long long)cog * 64 * r_co);
+                                                                         (long long)cog * COG * r_co);
       const auto rrs = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ru >> 32)) << 32) |
                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ru)), 0, 0x7fffff00, RS_FLAGS);
@@ -1058,7 +1092,7 @@ template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false>
 int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   using C = BCfg<COT, PXW>;
   const int tiles_x = cmf_ceil_div(a.W, C::TW), tiles = tiles_x * cmf_ceil_div(a.H, C::TH);
-  const int nslices = a.nc / 16, ncog = cmf_ceil_div(a.cout, 64);
+  const int nslices = a.nc / 16, ncog = (F16 && COT == 2) ? a.cout / 32 : cmf_ceil_div(a.cout, 64);
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
   auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE, F16, FRES>;
@@ -1168,7 +1202,11 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
 }
 
 extern "C" int cmf_conv_tangent_f16x3(const cmf_conv_tangent_args* ap, void* stream) {
-  if (!ap) return CMF_EINVAL;
+  return cmf_conv_tangent_f16x3_item(ap, 0, stream);
+}
+
+extern "C" int cmf_conv_tangent_f16x3_item(const cmf_conv_tangent_args* ap, int item_channels, void* stream) {
+  if (!ap || (item_channels != 0 && item_channels != 32 && item_channels != 64)) return CMF_EINVAL;
   const cmf_conv_tangent_args& a = *ap;
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
   if (a.taps != 9 || a.cin % 32 || a.nc <= 0 || a.nc % 16 || a.cout % 64) return CMF_EINVAL;
@@ -1187,6 +1225,16 @@ extern "C" int cmf_conv_tangent_f16x3(const cmf_conv_tangent_args* ap, void* str
   if (!(t14 || t8)) return CMF_EINVAL;
   if (a.bias && a.cout > 64) return CMF_EINVAL;                 // the per-channel constants are fetched once per launch
   hipStream_t s = (hipStream_t)stream;
+  // items of 64 output channels -- or of 32 when that still leaves CUs without one (a 32-sample CIFAR shard: 64 -> 128 items; the
+  // 64-sample MNIST shard's 28 x 28 layers: 112 -> 224): a launch of one item per workgroup lasts one item, and half an item's
+  // MFMA work is the shorter item
+  const int TH = t14 ? 2 : 4, TW = t14 ? 14 : 8;
+  const long long items64 = (long long)(a.H / TH) * (a.W / TW) * (a.nc / 16) * (a.cout / 64) * a.np;
+  const bool half = item_channels ? item_channels == 32 : 2 * items64 <= cmf_device_cus();
+  if (half) {
+    if (a.r) return t14 ? launch<2, 7, 2, true, true>(a, s) : launch<2, 4, 2, true, true>(a, s);
+    return t14 ? launch<2, 7, 2, true>(a, s) : launch<2, 4, 2, true>(a, s);
+  }
   if (a.r) return t14 ? launch<4, 7, 2, true, true>(a, s) : launch<4, 4, 2, true, true>(a, s);
   return t14 ? launch<4, 7, 2, true>(a, s) : launch<4, 4, 2, true>(a, s);
 }

@@ -94,17 +94,14 @@ class KernelConfig:
              as few mask flips as exact fp32 products, profiles/r04_primal_precision_study.txt) at the bf16 MFMA rate;
              "f32" = exact fp32 MFMA (2.8x slower); "bf16x3" = bf16 split (~2^-16: ~15x more mask flips, median per-sample
              log-det / g_ij error 3e-6 / 1.4e-5 instead of 1e-6 / 2e-7 -- kept as an experiment, never the default)."""
-    __slots__ = ("tangent", "primal", "primal_min_items")
+    __slots__ = ("tangent", "primal")
 
-    def __init__(self, tangent="bf16x3", primal="f16x3", primal_min_items=96):
+    def __init__(self, tangent="bf16x3", primal="f16x3"):
         assert tangent in ("bf16x3", "f32") and primal in ("f16x3", "f32", "bf16x3")
         self.tangent, self.primal = tangent, primal
-        #: launches of the fp16 split primal kernel with fewer (tile, sample group) work items than this use the fp32 kernel's
-        #: small-grid forms instead (``_resnet_primal_grouped``)
-        self.primal_min_items = int(primal_min_items)
 
     def __repr__(self):
-        return f"KernelConfig(tangent={self.tangent!r}, primal={self.primal!r}, primal_min_items={self.primal_min_items})"
+        return f"KernelConfig(tangent={self.tangent!r}, primal={self.primal!r})"
 
 
 _DEFAULT_CONFIG = KernelConfig()
@@ -123,7 +120,7 @@ class scope:
     def __init__(self, config=None, **kw):
         cur = cfg()
         self.config = config if config is not None else KernelConfig(
-            **{**{"tangent": cur.tangent, "primal": cur.primal, "primal_min_items": cur.primal_min_items}, **kw})
+            **{**{"tangent": cur.tangent, "primal": cur.primal}, **kw})
 
     def __enter__(self):
         if not hasattr(_tls, "cfg"):
@@ -362,7 +359,7 @@ def conv_primal(x_ptr_t, x_off, x_b, x_c, x_px, weight, taps, bias, y, y_b, y_c,
 def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_px, np_, cin, cout, H, W, nc,
                  fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, res_t=None, transpose=False, bias=None, f_group=1,
                  x_sl=16, y_sl=16, precision=None, y_off=0, res_off=0, fo=None, fo_np=0, fo_co=0, fo_px=0, fomode=F_NONE,
-                 mask_out=None, mask_np=0, amax_in=None, amax_out=None):
+                 mask_out=None, mask_np=0, amax_in=None, amax_out=None, item_channels=0):
     """``fo`` = OUTPUT-side factor (reverse sweep, fp32 kernel only); ``y_off`` / ``res_off`` = element offsets into
     ``y_t`` / ``res_t`` (in-place accumulation into a strided view of a larger tensor).  ``precision`` "f16x3": the fp16 split
     kernel of the primal pass (``amax_in`` / ``amax_out``: one-float device tensors, the input-range chain)."""
@@ -399,6 +396,8 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     fn, what = ((lib.cmf_conv_tangent_f16x3, "cmf_conv_tangent_f16x3") if f16 else
                 (lib.cmf_conv_tangent_bf16x3, "cmf_conv_tangent_bf16x3") if split else (lib.cmf_conv_tangent, "cmf_conv_tangent"))
     launch = lambda: _lib.check(fn(C.byref(a), _stream()), what)
+    if f16 and item_channels:                               # tests / probes: the item size cmf_conv_tangent_f16x3 would pick itself
+        launch = lambda: _lib.check(lib.cmf_conv_tangent_f16x3_item(C.byref(a), int(item_channels), _stream()), "cmf_conv_tangent_f16x3_item")
     if fmode == F_SELF_RELU and not f16 and getattr(_lib._tls, "sink", None) is not None:
         run = launch
 
@@ -1131,13 +1130,8 @@ def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts
     new = lambda: torch.empty(G * hid * HW * 16, dtype=torch.float32, device=dev)
     train = need_acts == "train"                          # ActList: the "bits" form + the grouped floats
     prec = cfg().primal
-    if prec == "f16x3":
-        # the fp16 split kernel works on whole 64-channel groups, one persistent workgroup per CU streaming (tile, sample group)
-        # items: below ~100 items (a 32-sample CIFAR shard: 64; the 14 x 14 layers of a 64-sample MNIST shard: 28) the launch is one
-        # item's latency either way and the fp32 kernel's small-grid forms (16 / 32 channels per workgroup) are as fast
-        tiles = (H // 2) * (W // 14) if W % 14 == 0 else (H // 4) * (W // 8)
-        if hid % 64 or G * tiles < cfg().primal_min_items:
-            prec = "f32"
+    if prec == "f16x3" and hid % 64:
+        prec = "f32"                                      # the fp16 split kernel works on whole 64-channel groups
     bits = (need_acts == "bits" or train) and prec != "bf16x3" and hid % 16 == 0
     a = primal_regroup(a0, True)
     acts, masks = [a], []

@@ -142,6 +142,11 @@ int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* a, void* stream);
  * values, as cmf_conv_tangent writes them).  `w` must come from cmf_pack_weight_f16x3.                                        */
 int cmf_pack_weight_f16x3(const float* w, void* out, int cout, int cin, int transpose, long long* out_bytes, void* stream);
 int cmf_conv_tangent_f16x3(const cmf_conv_tangent_args* a, void* stream);
+/* the same with the work-item size chosen by the caller: item_channels = 64 (a workgroup's item is a pixel tile x 16 samples x 64
+ * output channels), 32 (half of a 64-channel group per item: twice the items, for launches that would leave most CUs without one)
+ * or 0 = cmf_conv_tangent_f16x3's own choice (32 when the 64-channel items number at most half the CUs).  Results are
+ * bit-identical between the two sizes.                                                                                       */
+int cmf_conv_tangent_f16x3_item(const cmf_conv_tangent_args* a, int item_channels, void* stream);
 /* out[0] = max(out[0], max_i |x[i]|) over n floats (out is NOT cleared: the caller zeroes it or chains several tensors).   */
 int cmf_absmax(const float* x, long long n, float* out, void* stream);
 
