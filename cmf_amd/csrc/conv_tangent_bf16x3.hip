@@ -133,7 +133,13 @@ __device__ __forceinline__ int xslot(int col, int pix) { return (((col & 3) << 2
 template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false>
 __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
                                                                        int nslices, int ncog, int total) {
-  static_assert(!F16 || (MODE == 2 && (COT == 4 || COT == 2)), "the fp16 variant is the primal pass: SELF mode");
+  static_assert(!F16 || ((MODE == 2 || MODE == 4) && (COT == 4 || COT == 2)), "the fp16 variant is the primal pass: SELF mode (forward) or 4 (backward)");
+  // BWD (F16 with MODE 4): the primal BACKWARD's data-gradient convs -- plain input (a cotangent, no relu on load), the packed
+  // adjoint operator, and  y = [fo > 0] . conv(x) + r  with fo a float tensor laid out like y (the forward activation whose relu
+  // the cotangent passes back through, per column = per sample) and an optional residual: both tiles are loaded in the FRES
+  // epilogue; no sign bits are written, *amax_out is raised to max |y|
+  constexpr bool BWD = F16 && MODE == 4;
+  static_assert(!BWD || FRES, "the backward form uses the epilogue with tile loads");
   // HALF (F16 with COT == 2): an item is 32 output channels of a 64-channel group, `cog` counts HALF groups -- twice the items for
   // launches that would leave most of the chip idle (a 32-sample CIFAR shard: 64 items of 64 channels for 256 CUs).  The weight
   // pack is the 64-channel one: a half reads two of the slab's four channel tiles.
@@ -146,9 +152,9 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   constexpr bool SELF = MODE == 2, RELU = MODE == 1, BITS = MODE == 3;   // 3 = relu' from a bit mask (CMF_F_RELU_BITS)
   // 4 = PLAIN: no input factor at all (no factor stream, like SELF, and no relu) and an optional OUTPUT-side relu' bit mask
   // applied at the store -- the reverse (cotangent) sweep: the adjoint of "mask, then conv" is "transposed conv, then mask"
-  constexpr bool PLAIN = MODE == 4 || MODE == 5;
+  constexpr bool PLAIN = !F16 && (MODE == 4 || MODE == 5);
   constexpr bool INPLACE = MODE == 5;                          // PLAIN with the output tensor as the (unmasked) residual: below
-  constexpr bool NOF = SELF || PLAIN;                            // no factor stream
+  constexpr bool NOF = SELF || PLAIN || BWD;                     // no factor stream
   constexpr int NF = NOF ? 0 : BITS ? 1 : 8;                     // factor loads per loader thread and chunk
   using C = BCfg<COT, PXW>;
   constexpr int CW = COT / 2, PW = C::PW;
@@ -708,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       }
     }
   };
-  auto store_pixel = [&](const Item& it, int p, f32x4 radd0, f32x4 radd1) __attribute__((always_inline)) {
+  auto store_pixel = [&](const Item& it, int p, f32x4 radd0, f32x4 radd1, f32x4 m0 = f32x4{}, f32x4 m1 = f32x4{}) __attribute__((always_inline)) {
     [[maybe_unused]] unsigned mbits = 0;
     [[maybe_unused]] f32x4 vst[CW];
 #pragma unroll
@@ -720,7 +726,12 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         if constexpr (inplace) vo = on ? yvoff : Y_DROP;
         else v = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if constexpr (HALF) v = v * oscale + ((it.cog & 1) ? bias_h1 : bias[c]);
+      if constexpr (BWD) {                                         // undo the scales, then the per-sample relu' of the forward activation
+        v = v * oscale;
+        const f32x4 mm = c == 0 ? m0 : m1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = mm[r] > 0.f ? v[r] : 0.f;
+      } else if constexpr (HALF) v = v * oscale + ((it.cog & 1) ? bias_h1 : bias[c]);
       else if constexpr (F16) v = v * oscale + bias[c];            // undo the operand scales (exact), then the bias
       else v += bias[c];                                           // per-channel constant (primal bias)
       if constexpr (FRES) v += c == 0 ? radd0 : radd1;             // the residual, once, after the products
@@ -730,10 +741,15 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         vst[c] = v;
         // inline asm on purpose (also the mask code below): written with builtins (fmaxf, __ballot + selects) this epilogue sent
         // hipcc's register allocation from 251 VGPRs to 256 + 118 spilled
-        asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(ymax) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        if constexpr (BWD)                                         // signed values feed the next conv: max |v|
+          asm volatile("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|" : "+v"(ymax) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        else
+          asm volatile("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(ymax) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
       }
     }
-    if constexpr (HALF) {
+    if constexpr (BWD) {
+      // no sign bits
+    } else if constexpr (HALF) {
       // one channel tile: the ballot's 16-bit quarter kq of register r IS sample 4 kq + r's word
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -981,20 +997,31 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       // epilogue with the residual: groups of GP pixels -- their residual tiles land in the registers the chunk's fragments just
       // freed (hipcc counts these waits itself: plain builtin loads, nothing else in flight), then scale + bias + residual,
       // stores, sign bits, running maximum per pixel
-      constexpr int GP = PW > 14 ? PW / 4 : PW / 2;               // 16-pixel waves hold 128 accumulators: smaller groups
+      // (BWD with 64-channel items: two tiles per pixel and channel tile -- smaller groups still)
+      constexpr int GP = BWD && CW == 2 ? (PW > 14 ? 4 : 2) : PW > 14 ? PW / 4 : PW / 2;
+      static_assert(PW % GP == 0, "whole groups");
       int np, slice, cog;
       {
         int tile;
         decode(item, tile, slice, cog, np);
       }
-      const unsigned long long ru = reinterpret_cast<unsigned long long>(a.r + (long long)np * a.r_np + (long long)slice * (a.r_sl ? a.r_sl : 16) +
-                                                                         (long long)cog * COG * r_co);
-      const auto rrs = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ru >> 32)) << 32) |
-                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ru)), 0, 0x7fffff00, RS_FLAGS);
+      auto tile_rsrc = [&](const float* base, bool on) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+        return __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u)), 0, on ? 0x7fffff00 : 0, RS_FLAGS);
+      };
+      const long long slo = (long long)slice * (a.r_sl ? a.r_sl : 16);
+      // BWD: the residual is optional (zero records: the loads return 0 without touching memory)
+      const auto rrs = tile_rsrc(a.r ? a.r + (long long)np * a.r_np + slo + (long long)cog * COG * r_co : a.y, a.r != nullptr);
+      [[maybe_unused]] const int fo_co = (int)a.fo_co, fo_px = (int)a.fo_px;
+      [[maybe_unused]] const int fovoff = 4 * ((cohalf * CW * 16 + cl) * fo_co + kq * 4);
+      [[maybe_unused]] const auto frs = tile_rsrc(BWD ? a.fo + (long long)np * a.fo_np + (long long)slice * (a.y_sl ? a.y_sl : 16) +
+                                                            (long long)cog * COG * fo_co : a.y, BWD);
 #pragma unroll
       for (int p0 = 0; p0 < PW; p0 += GP) {
         f32x4 rb[GP][CW];
+        [[maybe_unused]] f32x4 mb[GP][CW];
 #pragma unroll
         for (int q = 0; q < GP; ++q)
 #pragma unroll
@@ -1002,9 +1029,15 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
             const int p = p0 + q;
             rb[q][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 rrs, rvoff, cur.rpix + 4 * (((p / C::TW) * a.W + p % C::TW) * r_px + c * 16 * r_co), 0));
+            if constexpr (BWD)
+              mb[q][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                  frs, fovoff, 4 * ((cur.pix0 + (p / C::TW) * a.W + p % C::TW) * fo_px + c * 16 * fo_co), 0));
           }
 #pragma unroll
-        for (int q = 0; q < GP; ++q) store_pixel(cur, p0 + q, rb[q][0], rb[q][CW - 1]);
+        for (int q = 0; q < GP; ++q) {
+          if constexpr (BWD) store_pixel(cur, p0 + q, rb[q][0], rb[q][CW - 1], mb[q][0], mb[q][CW - 1]);
+          else store_pixel(cur, p0 + q, rb[q][0], rb[q][CW - 1]);
+        }
       }
     }
     cur = nxt;
@@ -1210,7 +1243,11 @@ extern "C" int cmf_conv_tangent_f16x3_item(const cmf_conv_tangent_args* ap, int 
   const cmf_conv_tangent_args& a = *ap;
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
   if (a.taps != 9 || a.cin % 32 || a.nc <= 0 || a.nc % 16 || a.cout % 64) return CMF_EINVAL;
-  if (a.fmode != CMF_F_SELF_RELU || a.fo) return CMF_EINVAL;      // the primal pass: the input's own relu, no output factor
+  // forward: the input's own relu, no output factor.  backward (data gradient): plain input, the adjoint pack, y = [fo > 0] . conv
+  // + r with fo a float tensor laid out like y (fomode CMF_F_SELF_RELU: cmf_conv_tangent's primal-backward form), no bias, no sign bits
+  const bool bwd = a.fmode == CMF_F_NONE && a.fo && a.fomode == CMF_F_SELF_RELU;
+  if (!bwd && (a.fmode != CMF_F_SELF_RELU || a.fo)) return CMF_EINVAL;
+  if (bwd && (a.bias || a.mask_out || (a.fo_np | a.fo_co | a.fo_px) % 4 || (uintptr_t)a.fo % 16)) return CMF_EINVAL;
   if (a.mask_out && (a.mask_np % 4 || (uintptr_t)a.mask_out % 4 || a.mask_np < (long long)a.H * a.W * (a.cout / 8) ||
                      16 * a.mask_np >= 0x7fffff00LL))
     return CMF_EINVAL;
@@ -1219,7 +1256,8 @@ extern "C" int cmf_conv_tangent_f16x3_item(const cmf_conv_tangent_args* ap, int 
   if (a.r && ((a.r_np | a.r_co | a.r_px) % 4 || ((uintptr_t)a.r % 16))) return CMF_EINVAL;
   const long long HW = (long long)a.H * a.W;
   if (!fits_int((a.cin + 8) * a.x_ci + HW * a.x_px + a.nc) || !fits_int((a.cout + 64) * a.y_co + HW * a.y_px + a.nc + 64) ||
-      (a.r && !fits_int((a.cout + 64) * a.r_co + HW * a.r_px + a.nc)) || HW > (1 << 24))
+      (a.r && !fits_int((a.cout + 64) * a.r_co + HW * a.r_px + a.nc)) ||
+      (bwd && !fits_int((a.cout + 64) * a.fo_co + HW * a.fo_px + a.nc)) || HW > (1 << 24))
     return CMF_ERANGE;
   const bool t14 = a.W % 14 == 0 && a.H % 2 == 0, t8 = a.W % 8 == 0 && a.H % 4 == 0;
   if (!(t14 || t8)) return CMF_EINVAL;
@@ -1231,6 +1269,10 @@ extern "C" int cmf_conv_tangent_f16x3_item(const cmf_conv_tangent_args* ap, int 
   const int TH = t14 ? 2 : 4, TW = t14 ? 14 : 8;
   const long long items64 = (long long)(a.H / TH) * (a.W / TW) * (a.nc / 16) * (a.cout / 64) * a.np;
   const bool half = item_channels ? item_channels == 32 : 2 * items64 <= cmf_device_cus();
+  if (bwd) {
+    if (half) return t14 ? launch<2, 7, 4, true, true>(a, s) : launch<2, 4, 4, true, true>(a, s);
+    return t14 ? launch<4, 7, 4, true, true>(a, s) : launch<4, 4, 4, true, true>(a, s);
+  }
   if (half) {
     if (a.r) return t14 ? launch<2, 7, 2, true, true>(a, s) : launch<2, 4, 2, true, true>(a, s);
     return t14 ? launch<2, 7, 2, true>(a, s) : launch<2, 4, 2, true>(a, s);

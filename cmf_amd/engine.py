@@ -376,8 +376,11 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     split = (precision == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
              and ((fmode != F_NONE and fo is None) or
                   (fmode == F_NONE and (fo is None or (obits and (res_t is None or inplace) and cout % 64 == 0)))))
-    f16 = (precision == "f16x3" and fmode == F_SELF_RELU and fo is None and not transpose and cout % 64 == 0
-           and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout))
+    # fp16 split kernel: the primal pass's forward form (the input's own relu) or its backward form (plain cotangent in, per-column
+    # relu' of a float activation laid out like y on the way out, optional residual: net_primal_backward)
+    pbwd = fmode == F_NONE and fo is not None and not obits and fomode == F_SELF_RELU
+    f16 = (precision == "f16x3" and cout % 64 == 0 and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
+           and ((fmode == F_SELF_RELU and fo is None and not transpose) or (pbwd and bias is None and mask_out is None)))
     assert not obits or split, "bit-mask output factors are applied by the split-precision kernel only"
     if obits:
         fo, fo_np, fo_co, fo_px, fomode = fo.data, fo.np_bytes, 0, 0, F_RELU_BITS
@@ -410,7 +413,8 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     # algorithmic work of this launch: 2*cin*cout*taps FLOP per output pixel and Jacobian column; every input,
     # output and residual element crosses HBM once (4 bytes each)
     px = float(H) * W * nc * np_
-    TIMER.wrap(f"conv_tangent_t{taps}_ci{cin}_co{cout}" + ("_primal" if fmode == F_SELF_RELU else ""), 2.0 * cin * cout * taps * px,
+    TIMER.wrap(f"conv_tangent_t{taps}_ci{cin}_co{cout}" + ("_primal" if fmode == F_SELF_RELU else "_primal_bwd" if pbwd else ""),
+               2.0 * cin * cout * taps * px,
                4.0 * px * (cin + cout + (cout if res_t is not None else 0)), launch)
 
 
@@ -1451,6 +1455,11 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
             conv_tangent_wgrad(x_g, 0, *pn(hid), gy_g, 0, *pn(hid), _grad_of(grads, weight), 9, G, hid, hid, H, W, 16, fmode=F_SELF_RELU)
 
     tr = dict(transpose=True, precision="f32")
+    # hidden 3x3 data-gradient convs: the fp16 split kernel's backward form when the primal pass runs on it (KernelConfig.primal), with
+    # its own input-range chain: word 0 = max |da| by a reduction, the others raised by the conv that stores the cotangent
+    use16 = cfg().primal == "f16x3" and hid % 64 == 0 and _shape_ok_bf16x3(9, hid, W, True, H, hid)
+    rng = torch.zeros(2 * len(blocks) + 1, dtype=torch.float32, device=dev) if use16 else None
+    tr16 = lambda i: (dict(transpose=True, precision="f16x3", amax_in=rng[i:i + 1], amax_out=rng[i + 1:i + 2]) if use16 else tr)
     self_fo = lambda t: dict(fo=t, fo_np=hid * HW * 16, fo_co=HW * 16, fo_px=16, fomode=F_SELF_RELU)
     du = stanh_backward(dy, dg, y, g, net.weights, net.bias, _grad_of(grads, net.weights).view(-1), _grad_of(grads, net.bias).view(-1))
     kept = getattr(acts, "grouped", None) if Bp == B else None   # ActList: the forward pass's grouped tensors, no regrouping
@@ -1461,18 +1470,20 @@ def net_primal_backward(net, z, view, acts, y, g, dy, dg, grads, dz):
     channel_sum(du_g, *pn(cout), G, cout, HW, 16, _grad_of(grads, convf.bias))
     da = new(hid)
     conv_tangent(du_g, 0, *pn(cout), convf.weight, 1, da, *pn(hid), G, cout, hid, H, W, 16, **self_fo(a_g), **tr)
-    for k in reversed(range(len(blocks))):
+    if use16:
+        absmax(da, rng[0:1])
+    for j, k in enumerate(reversed(range(len(blocks)))):
         blk = blocks[k]
         a_in, c1 = gact(2 * k), gact(2 * k + 1)
         # a' = a + conv2(relu(c1)) + b2,  c1 = conv1(relu(a)) + b1
         hidden_wgrad(c1, da, blk.conv2.weight)
         hidden_bias_grad(da, blk.conv2.bias)
         dc1 = new(hid)
-        conv_tangent(da, 0, *pn(hid), blk.conv2.weight, 9, dc1, *pn(hid), G, hid, hid, H, W, 16, **self_fo(c1), **tr)
+        conv_tangent(da, 0, *pn(hid), blk.conv2.weight, 9, dc1, *pn(hid), G, hid, hid, H, W, 16, **self_fo(c1), **tr16(2 * j))
         hidden_wgrad(a_in, dc1, blk.conv1.weight)
         hidden_bias_grad(dc1, blk.conv1.bias)
         da2 = new(hid)
-        conv_tangent(dc1, 0, *pn(hid), blk.conv1.weight, 9, da2, *pn(hid), G, hid, hid, H, W, 16, res_t=da, **self_fo(a_in), **tr)
+        conv_tangent(dc1, 0, *pn(hid), blk.conv1.weight, 9, da2, *pn(hid), G, hid, hid, H, W, 16, res_t=da, **self_fo(a_in), **tr16(2 * j + 1))
         da = da2
     flush_wgrads()
     # a_0 = conv0(mask . z[view])   (no bias)

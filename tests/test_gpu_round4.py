@@ -84,6 +84,52 @@ def test_f16x3_primal_conv_values_masks_and_range_chain(H, W, scale):
         assert rel(E.primal_regroup(y2.view(G, -1), False).view(B, C, H, W), want) < 1e-6
 
 
+@pytest.mark.parametrize("H,W", [(14, 14), (28, 28), (16, 16), (8, 32)])
+@pytest.mark.parametrize("scale", [1.0, 1e-5])
+def test_f16x3_primal_backward_conv(H, W, scale):
+    """The data-gradient conv of the primal backward on the fp16-split kernel (16 samples in the column slots): plain cotangent in,
+    the ADJOINT operator packed from the layer's weight, per-sample relu' of the forward activation on the way out, optional
+    residual -- against float64 autograd of ``conv2d(relu(a))`` and against the fp32 kernel's form of the same launch; both work-item
+    sizes bit-identical; *amax_out = max |stored| (the next conv's input range).  ``scale``: cotangents far below fp16's range."""
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(H + W)
+    B, C, HW = 32, 64, H * W
+    G = B // 16
+    act = torch.randn(B, C, H, W, generator=gen)                     # the forward activation whose relu the cotangent passes through
+    w = torch.randn(C, C, 3, 3, generator=gen) / 24
+    gy = scale * torch.randn(B, C, H, W, generator=gen)              # cotangent of y = conv2d(relu(act), w)
+    res = scale * torch.randn(B, C, H, W, generator=gen)
+    a64 = act.double().requires_grad_(True)
+    F.conv2d(torch.relu(a64), w.double(), None, padding=1).backward(gy.double())
+    want = a64.grad                                                   # = [act > 0] . conv_transpose(gy, w)
+    gg, ag, rg = (E.primal_regroup(t.cuda(), True) for t in (gy, act, res))
+    wd = torch.nn.Parameter(w.cuda())
+    pn = (C * HW * 16, HW * 16, 16)
+    fo = dict(fo=ag, fo_np=C * HW * 16, fo_co=HW * 16, fo_px=16, fomode=E.F_SELF_RELU)
+    rng = torch.zeros(2, device="cuda")
+    E.absmax(gg, rng[0:1])
+    for with_res in (False, True):
+        ref = want + res.double() if with_res else want
+        outs = {}
+        for prec, item in (("f32", 0), ("f16x3", 64), ("f16x3", 32), ("f16x3", 0)):
+            yg = torch.full_like(gg, float("nan"))
+            rng[1] = 0
+            kw = dict(amax_in=rng[0:1], amax_out=rng[1:2], item_channels=item) if prec == "f16x3" else {}
+            with E.timing(lambda n: True) as timer:
+                E.conv_tangent(gg, 0, *pn, wd, 9, yg, *pn, G, C, C, H, W, 16, transpose=True, precision=prec, res_t=rg if with_res else None,
+                               **fo, **kw)
+            assert list(timer.by_name()) == ["conv_tangent_t9_ci64_co64_primal_bwd"]
+            outs[prec, item] = (E.primal_regroup(yg.view(G, -1), False).view(B, C, H, W), float(rng[1]))
+        e32 = rel(outs["f32", 0][0], ref)
+        for item in (64, 32, 0):
+            got, amax = outs["f16x3", item]
+            assert torch.equal(got, outs["f16x3", 64][0]) and amax == outs["f16x3", 64][1]
+            assert rel(got, ref) < 1e-6 and rel(got, ref) < 3 * e32 + 1e-7, (rel(got, ref), e32)
+            assert amax == float(got.abs().max())
+            if not with_res:
+                assert bool((got[act.cuda() <= 0] == 0).all())                     # masked exactly, not approximately
+
+
 def test_f16x3_pack_single_and_batched_agree():
     """cmf_pack_weight_f16x3 (two launches: scale, then pack) and kind 2 of cmf_pack_weights_batched write the same bytes, the
     trailer holds the power of two that puts max |w| in [2^11, 2^12), forward and adjoint operator."""

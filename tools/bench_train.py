@@ -2,26 +2,25 @@
 """Training step (forward + backward + flat Adam) of the C3 / C4 model on one MI355X: the secondary metric of SURVEY 8d
 ("train-mode fwd+bwd steps/s").  The reference trains MNIST with 64 samples per GPU (C4).
 
-  python tools/bench_train.py [--batch 64] [--steps 3]
+  python tools/bench_train.py [--batch 64] [--steps 3] [--config c3|c5]      (c5: CIFAR d = 128, train-mode Hutchinson + CG; batch 32)
 """
 import argparse, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
-ap.add_argument("--batch", type=int, default=64); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--config", default="c3", choices=["c3", "c5"]); ap.add_argument("--batch", type=int, default=None); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
 args = ap.parse_args()
 import bench
 from cmf_amd import engine as E
 from cmf_amd.optim import FlatOptimizer
 dev = torch.device("cuda", 0)
-cfg, schema, shape, sd, density = bench.make_model(dev)
-if schema[0]["type"] == "dequantization":                    # the noise is part of the synthetic input (as in bench.py)
-    density = density.module.density
+args.batch = args.batch or (64 if args.config == "c3" else 32)
+wl = bench.Workload(args.config, args.batch, 0, dev)
+density, x = wl.inner, wl.x                                  # the noise is part of the synthetic input (as in bench.py)
 density.train()
 opt = FlatOptimizer(density.parameters(), opt="adam", lr=1e-4)
-x = bench.synth_batch("mnist", shape, args.batch, 0, dev)
-kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=True, likelihood_wt=1., metric_wt=1.)
+kw = dict(add_reconstruction=True, add_offdiagonal_metric_reg=wl.off, likelihood_wt=1., metric_wt=1.)
 
 def step():
     opt.zero_grad()

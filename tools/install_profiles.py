@@ -31,6 +31,8 @@ if os.path.exists(os.path.join(src, "c5_train_variants.txt")):
     copied.append(f"{pre}_c5_train_variants.txt")
 cp(os.path.join(src, "mfma_sustained.txt"), f"{pre}_mfma_sustained.txt")
 cp(os.path.join(src, "stage_table.txt"), f"{pre}_stage_table.txt")
+cp(os.path.join(src, "c5_train_step.txt"), f"{pre}_c5_train_step.txt")
+cp(os.path.join(src, "f16x3_item_sizes.txt"), f"{pre}_f16x3_item_sizes.txt")
 if os.path.exists(os.path.join(src, "gpu_tests.log")):
     open(os.path.join(dst, f"{pre}_gpu_tests_summary.txt"), "w").write("".join(open(os.path.join(src, "gpu_tests.log")).readlines()[-3:]))
     copied.append(f"{pre}_gpu_tests_summary.txt")

@@ -32,4 +32,6 @@ timeout -k 10 300 python tools/exp_c5_train.py --modes 32 --B 256 --steps 2 >> $
 grep "C5 train" $out/c5_train_variants.txt
 timeout -k 10 200 python tools/ubench/mfmapower.py > $out/mfma_sustained.txt 2>&1
 timeout -k 10 200 python tools/stage_table.py c3 c5 > $out/stage_table.txt 2>&1
+timeout -k 10 300 python tools/bench_train.py --config c5 --steps 3 > $out/c5_train_step.txt 2>&1
+timeout -k 10 200 python tests/dev/f16x3_item_probe.py > $out/f16x3_item_sizes.txt 2>&1
 du -sh $out
