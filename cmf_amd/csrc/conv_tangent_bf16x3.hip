@@ -39,8 +39,17 @@ extern "C" int cmf_debug_read_stamps(void* out) {
       cmf_dbg_stamps[role][g][k] = t_;                                                            \
     }                                                                                             \
   } while (0)
+#define STAMP2(w, g, k)                                                                           \
+  do {                                                                                            \
+    if (blockIdx.x == 0 && lane == 0 && wave == (w)) {                                            \
+      unsigned long long t_;                                                                      \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+      cmf_dbg_stamps[2][g][k] = t_;                                                               \
+    }                                                                                             \
+  } while (0)
 #else
 #define STAMP(role, g, k) do {} while (0)
+#define STAMP2(w, g, k) do {} while (0)
 #endif
 
 namespace {
@@ -164,6 +173,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 4;
+  STAMP2(0, 8, 0);                                                 // diagnostic build: kernel entry / exit, prologue, epilogue
+  STAMP2(4, 9, 0);                                                 // (tools/read_stamps_f16.py)
   const int kq = lane >> 4, cl = lane & 15;
   const int nchunks = a.cin / 8;
   // F16: exact power-of-two scales (wave-uniform).  xscale puts the largest input in [2^13, 2^14); the packed weights carry
@@ -502,10 +513,13 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       prefetch(r1);
       prefetch(r2);
       prefetch_w();                                                // slab 0
+      STAMP2(4, 10, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP2(4, 10, 1);
       wait_x(r0);
       commit(r0, 0);
       prefetch_w();                                                // slab 1
+      STAMP2(4, 10, 2);
     }
     __syncthreads();                                               // stage 0 ready
     // iteration g: the MFMA waves consume stage g&1 (stream chunk g); set g%3 is free -> stream chunk g+3;
@@ -530,6 +544,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       iter(g + 2, r2, r0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // padding loads still in flight
+    STAMP2(4, 9, 1);
     return;
   }
 
@@ -1044,6 +1059,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     cur_yrs = nxt_yrs;
     cur_mrs = nxt_mrs;
   }
+  STAMP2(0, 11, 0);
   if constexpr (F16) {
     // The last item's "next residual" loads (zero-record descriptor) are still landing in the accumulator registers: drain them
     // and keep those registers allocated until then -- hipcc believes the inline-asm loads completed where they were issued, and
@@ -1059,6 +1075,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       if (lane == 0 && n_items > 0) atomicMax(reinterpret_cast<int*>(a.amax_out), __builtin_bit_cast(int, ymax));
     }
   }
+  STAMP2(0, 11, 1);
+  STAMP2(0, 8, 1);
 }
 
 // weight pre-split / pre-arrangement: out[cog][chunk][hl][s][cot 4][kq][co 16][8] bf16

@@ -139,7 +139,10 @@ int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* a, void* stream);
  * max |w| 2^k in [2^11, 2^12) (cmf_pack_weight_f16x3: same layout as cmf_pack_weight_bf16x3_t plus a 16-byte trailer
  * {2^k, 2^-k, 0, 0}; the max is taken on the device, no host synchronisation), the inputs times the power of two derived from
  * amax_in; the epilogue undoes both (exact), the residual enters scaled.  mask_out IS supported (the sign bits of the stored
- * values, as cmf_conv_tangent writes them).  `w` must come from cmf_pack_weight_f16x3.                                        */
+ * values, as cmf_conv_tangent writes them).  `w` must come from cmf_pack_weight_f16x3.
+ * BACKWARD form (the data-gradient convs of the same blocks under loss.backward(), trainer.py:213): fmode CMF_F_NONE, `w` the pack of
+ * the adjoint operator (transpose = 1), fo != NULL with fomode CMF_F_SELF_RELU -- a float tensor laid out like y (strides fo_np /
+ * fo_co / fo_px, columns included) -- and  y = [fo > 0] * conv(x) + r  per column; no bias, no mask_out; *amax_out = max |y|.          */
 int cmf_pack_weight_f16x3(const float* w, void* out, int cout, int cin, int transpose, long long* out_bytes, void* stream);
 int cmf_conv_tangent_f16x3(const cmf_conv_tangent_args* a, void* stream);
 /* the same with the work-item size chosen by the caller: item_channels = 64 (a workgroup's item is a pixel tile x 16 samples x 64

@@ -12,13 +12,15 @@ if [ -z "$SKIP_TESTS" ]; then                         # SKIP_TESTS=1: the suite 
   tail -3 $out/gpu_tests.log
   [ $rc -ne 0 ] && exit $rc
 fi
+# the PMC passes first: bench.py's roofline.traffic cites profiles/pmc_conv_tangent_bf16x3.json, stamped with the kernel source's hash
+bash tools/gpu_profile.sh $tag/eval > $out/eval_profile.log 2>&1 || { tail -5 $out/eval_profile.log; exit 1; }
+cp $out/eval/pmc_conv_tangent_bf16x3.json profiles/pmc_conv_tangent_bf16x3.json
 timeout -k 10 400 python bench.py > $out/bench_c3.json 2> $out/bench_c3.err || exit 1       # the default line: headline + every leg
 for c in c1 c2a c2b c5; do timeout -k 10 200 python bench.py --config $c > $out/bench_$c.json 2>/dev/null || exit 1; done
 timeout -k 10 200 python bench.py --config c5 --hutchinson > $out/bench_c5_hutch.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --train --batch 64 > $out/bench_train.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --config c5 --train > $out/bench_c5_train.json 2>/dev/null || exit 1
 timeout -k 10 300 python tools/bench_train.py --batch 64 --steps 3 > $out/train_step_b64.txt 2>&1 || exit 1
-bash tools/gpu_profile.sh $tag/eval > $out/eval_profile.log 2>&1 || { tail -5 $out/eval_profile.log; exit 1; }
 bash tools/gpu_profile_train.sh $tag/train > $out/train_profile.log 2>&1 || { tail -5 $out/train_profile.log; exit 1; }
 bash tools/gpu_profile_wgrad.sh $tag/wgrad > $out/wgrad_profile.log 2>&1 || { tail -5 $out/wgrad_profile.log; exit 1; }
 # C5 training step (low-rank Hutchinson backward): per-kernel totals, and one 256-sample step on the single GPU
