@@ -172,6 +172,11 @@ class phase:
         return False
 
 
+def tracing():
+    """True while a ``trace()`` is active on the calling thread."""
+    return getattr(_tls, "sink", None) is not None
+
+
 class role:
     """``with role("primal"):`` -- calls traced inside are recorded as "<symbol>:primal" (one kernel serving two stages: the fp32
     tangent conv also runs the sample-grouped primal convs of small shards)."""

@@ -401,7 +401,7 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     launch = lambda: _lib.check(fn(C.byref(a), _stream()), what)
     if f16 and item_channels:                               # tests / probes: the item size cmf_conv_tangent_f16x3 would pick itself
         launch = lambda: _lib.check(lib.cmf_conv_tangent_f16x3_item(C.byref(a), int(item_channels), _stream()), "cmf_conv_tangent_f16x3_item")
-    if fmode == F_SELF_RELU and not f16 and getattr(_lib._tls, "sink", None) is not None:
+    if fmode == F_SELF_RELU and not f16 and _lib.tracing():
         run = launch
 
         def launch():                                       # traced: a primal launch of a tangent kernel (bench.py's stages)
