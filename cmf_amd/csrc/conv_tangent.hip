@@ -362,6 +362,106 @@ int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
 
 inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 29); }   // element offsets; x4 bytes must fit 32 bits
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// THIN-INPUT 3x3 tangent conv -- a coupler network's FIRST conv (networks.py:40-47: 1 - 3 input channels -> the hidden width) for all
+// Jacobian columns: 18 * cin flop per output value against 4 B written, i.e. an HBM WRITE stream (6.6 GB per launch at the headline
+// shape), not matrix work.  On the MFMA kernel above its K dimension is mostly padding and it wrote at 3.6 TB/s; a fill of the same bytes
+// runs at 5.6.  Here: plain fp32 FMAs.  One WAVE per (sample, image row, 16-column slice, 64-channel group); the three input rows it
+// needs (times the input factor, zero rows / columns outside the image) are staged once in the wave's own LDS region and read back as
+// 16-byte broadcasts (4 distinct addresses per instruction); lane (cl = lane / 4, q = lane % 4) owns channels cl + 16 j (j = 0..3) x
+// columns 4 q .. 4 q + 3 of every pixel, so each of its four stores per pixel is 16 B of a CONTIGUOUS KiB in the slice-major hidden layout
+// (y_co = 16).  Weights: 36 * cin registers per lane, read from cmf_pack_weight's image.  No barriers (waves are independent).
+template <int CIN, int NJ>
+__global__ __launch_bounds__(256) void conv_tangent_thin_kernel(cmf_conv_tangent_args a, int nslices, int ncog, int cin_pad,
+                                                                 long long total_waves) {
+  // NJ = 16-channel tiles per wave: 4 (a whole 64-channel group) for one input channel, 2 for two or three -- the weights are
+  // 9 * CIN * NJ registers per lane (twice that as hipcc keeps them: pairs for v_pk_fma_f32); `cog` counts groups of 16 NJ channels
+  extern __shared__ __attribute__((aligned(16))) float thin_rows[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long gw = (long long)blockIdx.x * 4 + wave;
+  if (gw >= total_waves) return;                                   // whole waves only: nothing below synchronises
+  long long t = gw;
+  const int slice = (int)(t % nslices);
+  t /= nslices;
+  const int cog = (int)(t % ncog);
+  t /= ncog;
+  const int y = (int)(t % a.H), np = (int)(t / a.H);
+  const int q = lane & 3, cl = lane >> 2, W = a.W, WP = W + 2;
+  float* rows = thin_rows + (long long)wave * CIN * 3 * WP * 16;   // [ci][r][x + 1][16 columns]
+  // stage: piece = (ci, r, x, column quad); out-of-image rows and the two border columns are zeros
+  const float* xb = a.x + (long long)np * a.x_np + (long long)slice * (a.x_sl ? a.x_sl : 16);
+  const bool raw = a.fmode == CMF_F_RAW;
+  const float* fb = raw ? a.f + (long long)np * a.f_np : nullptr;
+#pragma unroll 2
+  for (int i = lane; i < CIN * 3 * WP * 4; i += 64) {
+    const int qq = i & 3, xx = (i >> 2) % WP - 1, rr = ((i >> 2) / WP) % 3, ci = (i >> 2) / (3 * WP);
+    const int yy = y - 1 + rr;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (yy >= 0 && yy < a.H && xx >= 0 && xx < W) {
+      const long long px = (long long)yy * W + xx;
+      v = *reinterpret_cast<const f32x4*>(xb + ci * a.x_ci + px * a.x_px + qq * 4);
+      if (raw) v *= fb[ci * a.f_ci + px * a.f_px];
+    }
+    *reinterpret_cast<f32x4*>(rows + ((ci * 3 + rr) * WP + xx + 1) * 16 + qq * 4) = v;
+  }
+  const int co0 = cog * NJ * 16 + cl;                              // this lane's first output channel (launcher: cout % 64 == 0)
+  float w[NJ][CIN][9];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int co = co0 + j * 16;
+        w[j][ci][tap] = a.w[(((long long)(co >> 6) * 9 + tap) * cin_pad + ci) * 64 + (co & 63)];
+      }
+  float* yb = a.y + (long long)np * a.y_np + (long long)slice * (a.y_sl ? a.y_sl : 16) + (long long)co0 * a.y_co + q * 4;
+  __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): the wave's own LDS writes (no barrier needed)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+  for (int x = 0; x < W; ++x) {
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(rows + ((ci * 3 + r) * WP + x + c) * 16 + q * 4);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[j] += w[j][ci][r * 3 + c] * v;
+        }
+    float* yp = yb + ((long long)y * W + x) * a.y_px;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(yp + (long long)j * 16 * a.y_co) = acc[j];
+  }
+}
+
+// shapes the thin kernel takes: everything else stays on the MFMA kernel
+inline bool thin_ok(const cmf_conv_tangent_args& a) {
+  return a.taps == 9 && a.cin <= 3 && a.cout % 64 == 0 && !a.fo && !a.r && !a.bias && !a.mask_out &&
+         (a.fmode == CMF_F_NONE || (a.fmode == CMF_F_RAW && a.f_group <= 1)) &&
+         (long long)4 * 3 * (a.W + 2) * a.cin * 64 <= 96 * 1024;
+}
+
+int launch_thin(const cmf_conv_tangent_args& a, hipStream_t s) {
+  const int nj = a.cin == 1 ? 4 : 2;
+  const int nslices = a.nc / 16, ncog = a.cout / (16 * nj), cin_pad = (a.cin + 7) / 8 * 8;
+  const long long waves = (long long)a.np * a.H * ncog * nslices;
+  if ((waves + 3) / 4 > 0x7fffffffLL) return CMF_ERANGE;
+  const int lds = 4 * 3 * (a.W + 2) * a.cin * 64;
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  switch (a.cin) {
+    case 1: hipLaunchKernelGGL((conv_tangent_thin_kernel<1, 4>), grid, dim3(256), lds, s, a, nslices, ncog, cin_pad, waves); break;
+    case 2: hipLaunchKernelGGL((conv_tangent_thin_kernel<2, 2>), grid, dim3(256), lds, s, a, nslices, ncog, cin_pad, waves); break;
+    default: hipLaunchKernelGGL((conv_tangent_thin_kernel<3, 2>), grid, dim3(256), lds, s, a, nslices, ncog, cin_pad, waves); break;
+  }
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
@@ -386,6 +486,7 @@ extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
       HW > (1 << 24))
     return CMF_ERANGE;
   hipStream_t s = (hipStream_t)stream;
+  if (thin_ok(a)) return launch_thin(a, s);                       // a coupler's first conv: an HBM write stream, VALU kernel
   const bool seven = (a.taps == 9) ? (a.W % 14 == 0) : (HW % 28 == 0 && HW % 32 != 0);
   if (a.taps == 9 && !seven && a.W % 8 == 0 && a.cout % 64 == 0) {
     // tiny grids on 8-multiple widths (the primal pass of a 32-sample CIFAR shard: 32 tile items): 2 x 8 tiles instead of 2 x 16 --

@@ -63,6 +63,40 @@ def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, kerne
     assert rel(y, want) < 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,H,W,nc", [(1, 64, 28, 28, 64), (2, 64, 14, 14, 32), (3, 64, 32, 32, 16), (1, 128, 5, 14, 16), (3, 64, 8, 8, 128),
+                                             (2, 192, 6, 9, 16), (1, 64, 1, 1, 16), (3, 64, 3, 70, 16)])
+@pytest.mark.parametrize("fmode", ["none", "raw", "raw0"])
+@pytest.mark.parametrize("layout", ["panel", "slice"])
+def test_conv_tangent_thin_input(cin, cout, H, W, nc, fmode, layout):
+    """A coupler's FIRST conv (1 - 3 input channels -> 64-channel groups, no residual): cmf_conv_tangent runs it on the VALU
+    write-stream kernel (conv_tangent_thin_kernel) instead of the MFMA one.  Against float64 ``F.conv2d``; input factor none, a
+    per-sample RAW factor, and the checkerboard mask's form (RAW with f_np = 0: one plane for every sample); odd image sizes, one
+    pixel, more than one channel group, 1 / 2 / 8 column slices; panel input -> slice-major hidden output as net_tangent issues it."""
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(cin * 100 + H + W)
+    B, HW = 3, H * W
+    w = torch.randn(cout, cin, 3, 3, generator=gen) / (cin * 9) ** 0.5
+    x = torch.randn(B, cin, H, W, nc, generator=gen)
+    fac = (torch.rand(B if fmode == "raw" else 1, cin, H, W, generator=gen) > 0.4).float() * 1.5
+    xin = x * fac.unsqueeze(-1) if fmode != "none" else x
+    want = F.conv2d(xin.permute(0, 4, 1, 2, 3).reshape(B * nc, cin, H, W).double(), w.double(), padding=1)
+    want = want.reshape(B, nc, cout, H, W).permute(0, 2, 3, 4, 1)
+    wd = torch.nn.Parameter(w.cuda())
+    S = nc // 16
+    if layout == "panel":
+        st, sl, back = (cout * HW * nc, HW * nc, nc), 16, (lambda t: t.reshape(B, cout, H, W, nc))
+    else:
+        st, sl = (cout * HW * nc, 16, cout * nc), cout * 16
+        back = lambda t: t.reshape(B, HW, S, cout, 16).permute(0, 3, 1, 2, 4).reshape(B, cout, H, W, nc)
+    y = torch.full((B * cout * HW * nc,), float("nan"), device="cuda")
+    with E.timing(lambda n: True) as timer:
+        E.conv_tangent(x.cuda(), 0, cin * HW * nc, HW * nc, nc, wd, 9, y, *st, B, cin, cout, H, W, nc,
+                       fmode=E.F_NONE if fmode == "none" else E.F_RAW, f=None if fmode == "none" else fac.cuda(),
+                       f_np=cin * HW if fmode == "raw" else 0, f_ci=HW, f_px=1, y_sl=sl, precision="f32")
+    assert list(timer.by_name()) == [f"conv_tangent_t9_ci{cin}_co{cout}"]
+    assert rel(back(y), want) < 2e-6
+
+
 @pytest.mark.parametrize("cin,cout,H,W,taps,nc", [
     (64, 64, 14, 14, 9, 32), (64, 64, 6, 7, 9, 64), (128, 64, 5, 9, 9, 32), (64, 128, 28, 28, 9, 64), (2, 64, 14, 14, 9, 16), (1, 64, 8, 8, 9, 16), (64, 4, 14, 14, 1, 32),
     (128, 64, 4, 14, 9, 16), (96, 130, 3, 5, 9, 16), (17, 40, 5, 7, 9, 32), (130, 70, 1, 37, 1, 16), (10, 128, 1, 50, 1, 16),
