@@ -363,7 +363,7 @@ int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
 inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 29); }   // element offsets; x4 bytes must fit 32 bits
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// THIN-INPUT 3x3 tangent conv -- a coupler network's FIRST conv (networks.py:40-47: 1 - 3 input channels -> the hidden width) for all
+// THIN-INPUT 3x3 tangent conv -- a coupler network's FIRST conv (networks.py:40-47: 1 - 2 input channels -> the hidden width) for all
 // Jacobian columns: 18 * cin flop per output value against 4 B written, i.e. an HBM WRITE stream (6.6 GB per launch at the headline
 // shape), not matrix work.  On the MFMA kernel above its K dimension is mostly padding and it wrote at 3.6 TB/s; a fill of the same bytes
 // runs at 5.6.  Here: plain fp32 FMAs.  One WAVE per (sample, image row, 16-column slice, 64-channel group); the three input rows it
@@ -374,8 +374,9 @@ inline bool fits_int(long long v) { return v >= 0 && v < (1LL << 29); }   // ele
 template <int CIN, int NJ>
 __global__ __launch_bounds__(256) void conv_tangent_thin_kernel(cmf_conv_tangent_args a, int nslices, int ncog, int cin_pad,
                                                                  long long total_waves) {
-  // NJ = 16-channel tiles per wave: 4 (a whole 64-channel group) for one input channel, 2 for two or three -- the weights are
-  // 9 * CIN * NJ registers per lane (twice that as hipcc keeps them: pairs for v_pk_fma_f32); `cog` counts groups of 16 NJ channels
+  // NJ = 16-channel tiles per wave: 4 (a whole 64-channel group) for one input channel, 2 for two -- the weights are
+  // 9 * CIN * NJ registers per lane (twice that as hipcc keeps them: pairs for v_pk_fma_f32); `cog` counts groups of 16 NJ channels.
+  // Three input channels (the first CIFAR level) were built and measured too: VALU-bound at 3.2 TB/s, no faster than the MFMA kernel.
   extern __shared__ __attribute__((aligned(16))) float thin_rows[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long gw = (long long)blockIdx.x * 4 + wave;
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void conv_tangent_thin_kernel(cmf_conv_tangent
 
 // shapes the thin kernel takes: everything else stays on the MFMA kernel
 inline bool thin_ok(const cmf_conv_tangent_args& a) {
-  return a.taps == 9 && a.cin <= 3 && a.cout % 64 == 0 && !a.fo && !a.r && !a.bias && !a.mask_out &&
+  return a.taps == 9 && a.cin <= 2 && a.cout % 64 == 0 && !a.fo && !a.r && !a.bias && !a.mask_out &&
          (a.fmode == CMF_F_NONE || (a.fmode == CMF_F_RAW && a.f_group <= 1)) &&
          (long long)4 * 3 * (a.W + 2) * a.cin * 64 <= 96 * 1024;
 }
@@ -453,11 +454,8 @@ int launch_thin(const cmf_conv_tangent_args& a, hipStream_t s) {
   if ((waves + 3) / 4 > 0x7fffffffLL) return CMF_ERANGE;
   const int lds = 4 * 3 * (a.W + 2) * a.cin * 64;
   const dim3 grid((unsigned)((waves + 3) / 4));
-  switch (a.cin) {
-    case 1: hipLaunchKernelGGL((conv_tangent_thin_kernel<1, 4>), grid, dim3(256), lds, s, a, nslices, ncog, cin_pad, waves); break;
-    case 2: hipLaunchKernelGGL((conv_tangent_thin_kernel<2, 2>), grid, dim3(256), lds, s, a, nslices, ncog, cin_pad, waves); break;
-    default: hipLaunchKernelGGL((conv_tangent_thin_kernel<3, 2>), grid, dim3(256), lds, s, a, nslices, ncog, cin_pad, waves); break;
-  }
+  if (a.cin == 1) hipLaunchKernelGGL((conv_tangent_thin_kernel<1, 4>), grid, dim3(256), lds, s, a, nslices, ncog, cin_pad, waves);
+  else hipLaunchKernelGGL((conv_tangent_thin_kernel<2, 2>), grid, dim3(256), lds, s, a, nslices, ncog, cin_pad, waves);
   CMF_LAUNCH_CHECK();
   return 0;
 }

@@ -113,7 +113,7 @@ typedef struct {
                                                    atomically raised to max(y) over the stored values (the caller zeroes it: the next
                                                    conv's amax_in, whose relu-on-load ignores negative values); NULL = off              */
 } cmf_conv_tangent_args;
-/* (A launch with taps == 9, cin <= 3, cout % 64 == 0, no residual / bias / output factor / mask_out and fmode NONE or RAW -- the
+/* (A launch with taps == 9, cin <= 2, cout % 64 == 0, no residual / bias / output factor / mask_out and fmode NONE or RAW -- the
  * first conv of a coupler network, networks.py:40-47 -- is an HBM write stream and runs on a VALU kernel instead of the MFMA one:
  * same contract, fp32 FMAs.)                                                                                                     */
 int cmf_conv_tangent(const cmf_conv_tangent_args* a, void* stream);
