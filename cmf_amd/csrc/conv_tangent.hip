@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void conv_tangent_thin_kernel(cmf_conv_tangent
 inline bool thin_ok(const cmf_conv_tangent_args& a) {
   return a.taps == 9 && a.cin <= 2 && a.cout % 64 == 0 && !a.fo && !a.r && !a.bias && !a.mask_out &&
          (a.fmode == CMF_F_NONE || (a.fmode == CMF_F_RAW && a.f_group <= 1)) &&
-         (long long)4 * 3 * (a.W + 2) * a.cin * 64 <= 96 * 1024;
+         (long long)4 * 3 * (a.W + 2) * a.cin * 64 <= 64 * 1024;      // the four waves' row images: within the default dynamic-LDS limit
 }
 
 int launch_thin(const cmf_conv_tangent_args& a, hipStream_t s) {

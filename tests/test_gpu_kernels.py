@@ -64,7 +64,8 @@ def test_conv_tangent(cin, cout, H, W, taps, nc, fmode, precision, layout, kerne
 
 
 @pytest.mark.parametrize("cin,cout,H,W,nc", [(1, 64, 28, 28, 64), (2, 64, 14, 14, 32), (3, 64, 32, 32, 16), (1, 128, 5, 14, 16), (3, 64, 8, 8, 128),
-                                             (2, 192, 6, 9, 16), (1, 64, 1, 1, 16), (3, 64, 3, 70, 16)])
+                                             (2, 192, 6, 9, 16), (1, 64, 1, 1, 16), (3, 64, 3, 70, 16),
+                                             (2, 64, 3, 39, 16), (1, 64, 2, 90, 16)])     # the widest row image the VALU kernel stages / one beyond
 @pytest.mark.parametrize("fmode", ["none", "raw", "raw0"])
 @pytest.mark.parametrize("layout", ["panel", "slice"])
 def test_conv_tangent_thin_input(cin, cout, H, W, nc, fmode, layout):
