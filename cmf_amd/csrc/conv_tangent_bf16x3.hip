@@ -39,6 +39,20 @@ extern "C" int cmf_debug_read_stamps(void* out) {
       cmf_dbg_stamps[role][g][k] = t_;                                                            \
     }                                                                                             \
   } while (0)
+// ... and of EVERY workgroup: s_memrealtime (the chip-wide 100 MHz counter) at entry and at the exit of its MFMA wave 0
+// (tools/read_wg_span.py: how evenly the persistent workgroups finish their equal shares)
+__device__ unsigned long long cmf_dbg_wg_span[1024][2];
+extern "C" int cmf_debug_read_wg_span(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cmf_dbg_wg_span), sizeof(cmf_dbg_wg_span));
+}
+#define SPAN(k)                                                                                   \
+  do {                                                                                            \
+    if (lane == 0 && wave == 0 && blockIdx.x < 1024) {                                            \
+      unsigned long long t_;                                                                      \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+      cmf_dbg_wg_span[blockIdx.x][k] = t_;                                                        \
+    }                                                                                             \
+  } while (0)
 #define STAMP2(w, g, k)                                                                           \
   do {                                                                                            \
     if (blockIdx.x == 0 && lane == 0 && wave == (w)) {                                            \
@@ -50,6 +64,7 @@ extern "C" int cmf_debug_read_stamps(void* out) {
 #else
 #define STAMP(role, g, k) do {} while (0)
 #define STAMP2(w, g, k) do {} while (0)
+#define SPAN(k) do {} while (0)
 #endif
 
 namespace {
@@ -173,6 +188,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 4;
+  SPAN(0);
   STAMP2(0, 8, 0);                                                 // diagnostic build: kernel entry / exit, prologue, epilogue
   STAMP2(4, 9, 0);                                                 // (tools/read_stamps_f16.py)
   const int kq = lane >> 4, cl = lane & 15;
@@ -1077,6 +1093,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   }
   STAMP2(0, 11, 1);
   STAMP2(0, 8, 1);
+  SPAN(1);
 }
 
 // weight pre-split / pre-arrangement: out[cog][chunk][hl][s][cot 4][kq][co 16][8] bf16
