@@ -409,6 +409,26 @@ def train_leg(steps, warmup, config, density, x, B, rank, world, device, off=Tru
                    "peak_memory_gib": peak, "gradient_reduction": reduce_shape if world > 1 else None}}
 
 
+def guarded(name, fn, world):
+    """A SECONDARY measurement must not cost the headline: on one rank an exception inside it is printed to stderr and recorded as
+    ``{"error": ...}`` in its place (the headline was timed before any leg ran).  With more ranks the legs contain collectives: a rank
+    that skipped one would leave the others waiting in it, so there the exception ends the rank and the launcher stops the job."""
+    if world > 1:
+        return fn()
+    try:
+        return fn()
+    except Exception as e:                                  # noqa: BLE001
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        print(f"[bench] secondary measurement {name!r} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        try:
+            import torch
+            torch.cuda.empty_cache()
+        except Exception:                                   # noqa: BLE001
+            pass
+        return {"error": f"{type(e).__name__}: {e}"[:400]}
+
+
 def dominant(rows):
     """Kernel family with the largest summed duration: (name, launches, total_ms, flops, bytes)."""
     name = max(rows, key=lambda k: rows[k][1])
@@ -642,7 +662,7 @@ def run_rank(args):
         legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph, primal=args.primal_precision)
     stages = None
     if rank == 0 and not args.train and not args.no_kernel_timer and not args.hutchinson:
-        stages = stages_leg(wl, 1e3 * dt / args.steps)
+        stages = guarded("stages", lambda: stages_leg(wl, 1e3 * dt / args.steps), 1)
     if default_run and world > 1:
         # the gradient bucket's two reduction shapes, then the reference's actual multi-GPU workload (DataParallel TRAINING, 64
         # samples per GPU = configs[3]'s shard) with the faster one.  Last on this model: the optimiser steps change its weights
@@ -652,26 +672,41 @@ def run_rank(args):
         legs["train"] = train_leg(args.leg_steps, 1, "c3", inner, x64, 64, rank, world, device, off, legs["grad_reduce"]["used"])
     f32 = None
     if default_run and world == 1:
-        if not args.no_f32_exact:
+        def f32_exact():
             # the same workload with the hidden tangent convs on exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): 3 timed steps
             set_kernels(wl.density, tangent="f32")
-            dt32, _, rows32, _ = eval_timed(wl, 1, 3, 1, None if args.no_kernel_timer else (lambda name: name == HIDDEN_CONV), None)
-            set_kernels(wl.density, tangent=args.precision)
-            f32 = {"value": 3 * B / dt32, "unit": "evals/s", "steps": 3, "warmup": 1, "ms_per_step": 1e3 * dt32 / 3, "dtype": "f32"}
+            try:
+                dt32, _, rows32, _ = eval_timed(wl, 1, 3, 1, None if args.no_kernel_timer else (lambda name: name == HIDDEN_CONV), None)
+            finally:
+                set_kernels(wl.density, tangent=args.precision)
+            out = {"value": 3 * B / dt32, "unit": "evals/s", "steps": 3, "warmup": 1, "ms_per_step": 1e3 * dt32 / 3, "dtype": "f32"}
             if rows32:
                 name, n, ms, fl, by = dominant(rows32)
                 tf = fl / (ms * 1e-3) / 1e12
-                f32.update(kernel="conv_tangent_kernel<9,4,7> (fp32 MFMA)", kernel_avg_ms=ms / n, kernel_tflops=tf,
+                out.update(kernel="conv_tangent_kernel<9,4,7> (fp32 MFMA)", kernel_avg_ms=ms / n, kernel_tflops=tf,
                            peak=FP32_MFMA_PEAK_TFLOPS, frac=tf / FP32_MFMA_PEAK_TFLOPS)
-        legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph, primal=args.primal_precision)
-        legs["c2b"] = eval_leg("c2b", 4096, rank, world, device, 20, 2, args.precision, "weak", graph=True)
-        wl5 = Workload("c5", 32, rank, device, args.precision, args.primal_precision)
-        legs["c5_train"] = train_leg(args.leg_steps, 1, "c5", wl5.inner, wl5.x, 32, rank, world, device, wl5.off)
-        del wl5
-        torch.cuda.empty_cache()
-        # last on this model: the optimiser steps change its weights (C3 model, the reference's 64-sample C4 shard)
-        x64 = synth_batch(dataset, shape, 64, rank, device)
-        legs["train"] = train_leg(args.leg_steps, 1, "c3", inner, x64, 64, rank, world, device, off)
+            return out
+
+        def c5_train():
+            wl5 = Workload("c5", 32, rank, device, args.precision, args.primal_precision)
+            try:
+                return train_leg(args.leg_steps, 1, "c5", wl5.inner, wl5.x, 32, rank, world, device, wl5.off)
+            finally:
+                del wl5
+                torch.cuda.empty_cache()
+
+        def train():
+            # last on this model: the optimiser steps change its weights (C3 model, the reference's 64-sample C4 shard)
+            x64 = synth_batch(dataset, shape, 64, rank, device)
+            return train_leg(args.leg_steps, 1, "c3", inner, x64, 64, rank, world, device, off)
+
+        if not args.no_f32_exact:
+            f32 = guarded("f32_exact", f32_exact, world)
+        legs["c5"] = guarded("c5", lambda: eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph,
+                                                     primal=args.primal_precision), world)
+        legs["c2b"] = guarded("c2b", lambda: eval_leg("c2b", 4096, rank, world, device, 20, 2, args.precision, "weak", graph=True), world)
+        legs["c5_train"] = guarded("c5_train", c5_train, world)
+        legs["train"] = guarded("train", train, world)
 
     if rank == 0:
         total = B * world * args.steps
@@ -706,7 +741,8 @@ def run_rank(args):
             if v is not None:
                 line[k] = v
         if world == 1 and args.cpu_batch > 0:
-            line["cpu_baseline"] = cpu_baseline(schema, shape, {k: v.cpu() for k, v in sd.items()}, args.cpu_batch, dataset, off, label)
+            line["cpu_baseline"] = guarded("cpu_baseline", lambda: cpu_baseline(schema, shape, {k: v.cpu() for k, v in sd.items()},
+                                                                                args.cpu_batch, dataset, off, label), 1)
         print(json.dumps(line), flush=True)
     if grouped:
         dist.destroy_process_group()

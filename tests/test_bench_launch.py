@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -64,3 +66,16 @@ def test_a_failing_rank_stops_its_siblings_and_a_deadline_bounds_the_launch(tmp_
     ok = tmp_path / "ok.py"
     ok.write_text("import os\nif os.environ['RANK'] == '0':\n    print('{\"value\": 1}')\n")
     assert bench.spawn_ranks(bench.parse_args(["--gpus", "2"]), [], script=str(ok)) == 0
+
+
+def test_a_failing_secondary_measurement_does_not_cost_the_line(capsys):
+    """bench.guarded: on one rank a secondary leg that raises is reported on stderr and recorded as {"error": ...}; with more ranks
+    (collectives inside the legs) the exception propagates so that the launcher stops the job instead of leaving ranks waiting."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.guarded("ok", lambda: {"value": 1}, 1) == {"value": 1}
+    out = bench.guarded("broken", lambda: 1 / 0, 1)
+    assert set(out) == {"error"} and "ZeroDivisionError" in out["error"]
+    assert "secondary measurement 'broken' failed" in capsys.readouterr().err
+    with pytest.raises(ZeroDivisionError):
+        bench.guarded("broken", lambda: 1 / 0, 2)
