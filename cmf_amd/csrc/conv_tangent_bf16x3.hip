@@ -222,9 +222,19 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     nbx = (G - xcd + 7) >> 3;
     jx = bid >> 3;
   }
+#ifdef CMF_DBG_REPEAT
+  // timing only: every workgroup walks its item list CMF_DBG_REPEAT times in ONE launch (same arguments, same outputs) -- what R
+  // launches cost without R - 1 of their fills and drains: the ceiling of one persistent launch per coupler network
+  const int n_real = jx < xlen ? (xlen - jx + nbx - 1) / nbx : 0;
+  const int n_items = n_real * CMF_DBG_REPEAT;
+#else
   const int n_items = jx < xlen ? (xlen - jx + nbx - 1) / nbx : 0;
+#endif
   const int total_chunks = n_items * nchunks;
   auto decode = [&](int item, int& tile, int& slice, int& cog, int& np) {
+#ifdef CMF_DBG_REPEAT
+    item = n_real > 0 ? item % n_real : 0;
+#endif
     int w = xstart + jx + item * nbx;
     slice = w % nslices;
     w /= nslices;
