@@ -135,8 +135,23 @@ class AffineCouplingBijection(Bijection):
         y, _, _ = E.net_primal(self.net, z, view, need_acts=False)
         E.acl_primal(z, y, self.maps(z.device), decode=False, lj=lj)
 
-    def decode_(self, z, T=None, lj=None, ncols=None):
+    # Structural zeros (``zero_in=True``, decided by ``FlowProgram`` from the layer list alone, never from data): every element
+    # this layer's network reads is known to be zero for the primal AND for every tangent column -- the channels
+    # ``SplitDensity.pad_inputs`` appended (split.py:50-52) in front of a coupler whose pass-through half is exactly those
+    # (acl.py:148-160,169-189 with reverse_mask).  Then the network's tangent output is identically zero, so no tangent network
+    # runs (x-dot_mod = e^{-s} v_mod, bit for bit what the full computation yields), and its primal output is the same for every
+    # sample (one sample group, read with stride 0).  The reference burns the cycles; 1 coupler in 10 of the image models.
+    def pass_elements(self):
+        """Flat element ids of z the coupler network reads (its "pass-through" input)."""
+        raise NotImplementedError
+
+    def decode_(self, z, T=None, lj=None, ncols=None, zero_in=False):
         view = self.view(z.device)
+        if zero_in and self.net.kind == "resnet":
+            y, g = E.net_primal_zero_input(self.net, view, z.shape[0], z.device)
+            if T is not None:
+                E.acl_tangent(T, None, z, y, g, self.maps(z.device))
+            return E.acl_primal(z, y, self.maps(z.device), decode=True, lj=lj)
         if ((T is None or (ncols is not None and ncols <= 15 and lj is None))
                 and E.mlp_coupler_supported(self.net, view, T, 2 * self.cmod)):
             return E.mlp_coupler(self.net, z, T, view, self.maps(z.device), decode=True, lj=lj, ncols=ncols)
@@ -149,10 +164,14 @@ class AffineCouplingBijection(Bijection):
         E.acl_primal(z, y, self.maps(z.device), decode=True, lj=lj)
 
     # reverse sweep (J^T w): primal decode that keeps what the adjoint needs, then the adjoint step ------------
-    def decode_ctx_(self, z):
+    def decode_ctx_(self, z, zero_in=False):
         view = self.view(z.device)
         zb = z.clone()
-        y, g, acts = E.net_primal(self.net, z, view, need_acts=True)
+        if zero_in and self.net.kind == "resnet":
+            y, g = E.net_primal_zero_input(self.net, view, z.shape[0], z.device)
+            acts = "zero-input"
+        else:
+            y, g, acts = E.net_primal(self.net, z, view, need_acts=True)
         E.acl_primal(z, y, self.maps(z.device), decode=True)
         return zb, y, g, acts
 
@@ -160,18 +179,23 @@ class AffineCouplingBijection(Bijection):
         """Adjoint of the tangent update of ``decode_`` on the cotangent stack ``Ct`` (in place)."""
         zb, y, g, acts = ctx
         dev = zb.device
+        if isinstance(acts, str):                          # zero_in: the rows the network reads are dropped by the split's adjoint
+            return E.acl_cotangent(Ct, None, zb, y, g, self.maps(dev))
         YC = E.Tangent(Ct.B, y[0].numel(), Ct.nc, self.layout, dev)
         YC.data.zero_()
         E.acl_cotangent(Ct, YC, zb, y, g, self.maps(dev))
         E.net_cotangent(self.net, YC, self.view(dev), acts, Ct)
 
     # training (SURVEY 8 f1): decode keeping what the backward needs, and the backward of that step ------------
-    def decode_train_(self, z, T, keep=True, nc_hint=None):
+    def decode_train_(self, z, T, keep=True, nc_hint=None, zero_in=False):
         """``decode_`` on (z, T) in place; returns the context ``decode_backward_`` consumes: the layer input, the network's
         outputs and activations and, with a tangent stack (``T`` not None), every layer's input tangent, the modified tangent
         rows before the update and the network's raw tangent.  ``keep=False`` (recomputation): only the layer's inputs (z and a
-        copy of T: 1/17 of the hidden tangents of a ResNet coupler) are kept and the context is rebuilt in the backward pass."""
-        if not keep and T is not None:
+        copy of T: 1/17 of the hidden tangents of a ResNet coupler) are kept and the context is rebuilt in the backward pass.
+        ``zero_in``: no tangent network, nothing saved for one (the primal network still runs on the whole batch: its
+        per-sample activations are what the primal weight gradients are accumulated from)."""
+        zero_in = zero_in and self.net.kind == "resnet"
+        if not keep and T is not None and not zero_in:
             ctx = ("recompute", z.clone(), E.Tangent(T.B, T.N, T.nc, T.layout, T.data.device, data=T.data[: T.B * T.N * T.nc].clone()))
             self.decode_(z, T)
             return ctx
@@ -181,23 +205,29 @@ class AffineCouplingBijection(Bijection):
         y, g, acts = E.net_primal(self.net, z, view, need_acts=E.train_acts_mode(self.net, view, z.shape[0], T, nc=nc_hint))
         saved = V = YT = None
         if T is not None:
-            saved = []
-            YT = E.net_tangent(self.net, T, view, acts, save=saved)
             V = E.modified_rows(T, maps)
+            if zero_in:
+                saved = "zero-input"
+            else:
+                saved = []
+                YT = E.net_tangent(self.net, T, view, acts, save=saved)
             E.acl_tangent(T, YT, z, y, g, maps)
         E.acl_primal(z, y, maps, decode=True)
         return zb, y, g, acts, saved, V, YT
 
-    def decode_tangent_from_ctx_(self, ctx, T, save=False):
+    def decode_tangent_from_ctx_(self, ctx, T, save=False, zero_in=False):
         """The tangent half of ``decode_train_`` on a context whose primal half is already there (``decode_train_(z, None)``):
         pushes ``T`` through the layer in place.  ``save=False``: nothing is kept (the d-column sweep that only feeds the Gram
         matrix); ``save=True``: returns the context ``decode_backward_`` consumes for THIS stack (the layer's primal state is
         shared, not recomputed) -- the low-rank Hutchinson backward runs both on one primal decode."""
         zb, y, g, acts = ctx[:4]
         view, maps = self.view(zb.device), self.maps(zb.device)
-        saved = [] if save else None
-        YT = E.net_tangent(self.net, T, view, acts, save=saved)
         V = E.modified_rows(T, maps) if save else None
+        if zero_in and self.net.kind == "resnet":
+            saved, YT = "zero-input", None
+        else:
+            saved = [] if save else None
+            YT = E.net_tangent(self.net, T, view, acts, save=saved)
         E.acl_tangent(T, YT, zb, y, g, maps)                 # zb: the layer input, i.e. z BEFORE the primal update
         return (zb, y, g, acts, saved, V, YT) if save else None
 
@@ -212,7 +242,14 @@ class AffineCouplingBijection(Bijection):
         view, maps = self.view(dev), self.maps(dev)
         dy = torch.zeros_like(y)
         dg = None
-        if Ct is not None:
+        zero_in = isinstance(saved, str)                   # no tangent network ran: s-dot = t-dot = 0 (decode_train_(zero_in=True))
+        if Ct is not None and zero_in:
+            # only the log-scale sees the tangent update (d/ds of e^{-s} v); no reverse sweep, no tangent weight gradients: the
+            # cotangent of the network's (zero) input tangent lands on rows the split's adjoint drops
+            dg = torch.zeros_like(g) if g is not None else None
+            E.acl_cross_terms(Ct, V, None, zb, y, g, maps, None, dy, dg)
+            E.acl_cotangent(Ct, None, zb, y, g, maps)
+        elif Ct is not None:
             dg = torch.zeros_like(g) if g is not None else None
             dz_ct = torch.zeros_like(zb)
             E.acl_cross_terms(Ct, V, YT, zb, y, g, maps, dz_ct, dy, dg)
@@ -222,7 +259,7 @@ class AffineCouplingBijection(Bijection):
             cross = {}
             E.net_cotangent(self.net, YC, view, acts, Ct, saved=saved, grads=grads, cross=cross)
         E.acl_primal_backward(dx, zb, y, maps, dy, decode=True)
-        if Ct is not None:
+        if Ct is not None and not zero_in:
             dx += dz_ct
         if self.net.kind == "resnet":
             E.net_primal_backward(self.net, zb, view, acts, y, g, dy, dg, grads, dx)
@@ -284,9 +321,13 @@ class Checkerboard2dAffineCouplingBijection(AffineCouplingBijection):
         self.register_buffer("mask", torch.from_numpy(mask))
         zi = np.flatnonzero(mask.reshape(-1) == 0)
         self._set_maps(zi, zi, cmod=C)          # the net sees all C channels: its output is indexed like z
+        self._pass_elements = np.flatnonzero(mask.reshape(-1) != 0)
 
     def view(self, device):
         return E.NetView(self.geom, cin=self.geom.C, mask=self.mask)
+
+    def pass_elements(self):
+        return self._pass_elements                           # the net reads mask . z (acl.py:48-52)
 
 
 class _ChannelwiseACL(AffineCouplingBijection):
@@ -301,6 +342,11 @@ class _ChannelwiseACL(AffineCouplingBijection):
     def view(self, device):
         off, step, n = self._pass
         return E.NetView(self.geom, cin=n, chan_off=off, chan_step=step)
+
+    def pass_elements(self):
+        off, step, n = self._pass
+        HW = self.geom.HW
+        return ((off + step * np.arange(n))[:, None] * HW + np.arange(HW)[None, :]).reshape(-1)
 
 
 class SplitChannelwiseAffineCouplingBijection(_ChannelwiseACL):

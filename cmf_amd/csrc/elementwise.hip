@@ -77,9 +77,13 @@ __global__ void acl_tangent_kernel(float* __restrict__ t, long long t_b, long lo
   const float gs = g ? g[b * y_b + rs] : 1.f, gt = g ? g[b * y_b + rt] : 1.f;
   const float es = expf(-s);
   f32x4* tp = reinterpret_cast<f32x4*>(t + b * t_b + (long long)rz * t_r) + c4;
+  const f32x4 v = *tp;
+  if (!yt) {                        // the network's tangent is identically zero (its input is structurally zero): s-dot = t-dot = 0
+    *tp = es * v;
+    return;
+  }
   const f32x4 sd = reinterpret_cast<const f32x4*>(yt + b * yt_b + (long long)rs * yt_r)[c4];
   const f32x4 td = reinterpret_cast<const f32x4*>(yt + b * yt_b + (long long)rt * yt_r)[c4];
-  const f32x4 v = *tp;
   *tp = es * (v - (zo * gs) * sd) - gt * td;
 }
 
@@ -101,8 +105,10 @@ __global__ void acl_cotangent_kernel(float* __restrict__ c, long long c_b, long 
   const float es = expf(-s);
   f32x4* cp = reinterpret_cast<f32x4*>(c + b * c_b + (long long)rz * c_r) + c4;
   const f32x4 v = *cp;
-  reinterpret_cast<f32x4*>(yc + b * yc_b + (long long)rt * yc_r)[c4] = (-gt) * v;
-  reinterpret_cast<f32x4*>(yc + b * yc_b + (long long)rs * yc_r)[c4] = (-(es * zo * gs)) * v;
+  if (yc) {                         // null: nobody reads the cotangent of the network's output (its input rows are dropped)
+    reinterpret_cast<f32x4*>(yc + b * yc_b + (long long)rt * yc_r)[c4] = (-gt) * v;
+    reinterpret_cast<f32x4*>(yc + b * yc_b + (long long)rs * yc_r)[c4] = (-(es * zo * gs)) * v;
+  }
   *cp = es * v;
 }
 
@@ -176,6 +182,12 @@ __global__ __launch_bounds__(256) void acl_cross_terms_kernel(const float* __res
   const float* sp = yt + b * yt_b + (long long)rs * yt_r;
   const float* tp = yt + b * yt_b + (long long)rt * yt_r;
   float a_s = 0.f, a_z = 0.f, a_gs = 0.f, a_gt = 0.f;
+  if (!yt) {                        // s-dot = t-dot = 0: only the log-scale sees the tangent update, out = es v
+    for (int k = lane; k < nc; k += 64) a_s -= cp[k] * es * vp[k];
+    a_s = wave_sum(a_s);
+    if (lane == 0) dy[b * y_b + rs] += a_s;
+    return;
+  }
   for (int k = lane; k < nc; k += 64) {
     const float cv = cp[k], sd = sp[k];
     a_s -= cv * es * (vp[k] - zo * gs * sd);
@@ -386,8 +398,8 @@ int cmf_acl_primal(float* z, long long z_b, const float* y, long long y_b, const
 int cmf_acl_tangent(float* t, long long t_b, long long t_r, const float* yt, long long yt_b, long long yt_r, int nc,
                     const float* z, long long z_b, const float* y, long long y_b, const float* g, const int* zi,
                     const int* si, const int* ti, int n_mod, int B, void* stream) {
-  if (!t || !yt || !z || !y || !zi || !si || !ti || n_mod <= 0 || B <= 0 || nc <= 0 || nc % 4) return CMF_EINVAL;
-  if ((t_b | t_r | yt_b | yt_r) % 4 || (uintptr_t)t % 16 || (uintptr_t)yt % 16) return CMF_EINVAL;
+  if (!t || !z || !y || !zi || !si || !ti || n_mod <= 0 || B <= 0 || nc <= 0 || nc % 4) return CMF_EINVAL;
+  if ((t_b | t_r) % 4 || (uintptr_t)t % 16 || (yt && ((yt_b | yt_r) % 4 || (uintptr_t)yt % 16))) return CMF_EINVAL;
   const long long total = (long long)B * n_mod * (nc / 4);
   hipLaunchKernelGGL(acl_tangent_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, t, t_b, t_r, yt, yt_b,
                      yt_r, nc / 4, z, z_b, y, y_b, g, zi, si, ti, n_mod, total);
@@ -398,8 +410,8 @@ int cmf_acl_tangent(float* t, long long t_b, long long t_r, const float* yt, lon
 int cmf_acl_cotangent(float* c, long long c_b, long long c_r, float* yc, long long yc_b, long long yc_r, int nc,
                       const float* z, long long z_b, const float* y, long long y_b, const float* g, const int* zi,
                       const int* si, const int* ti, int n_mod, int B, void* stream) {
-  if (!c || !yc || !z || !y || !zi || !si || !ti || n_mod <= 0 || B <= 0 || nc <= 0 || nc % 4) return CMF_EINVAL;
-  if ((c_b | c_r | yc_b | yc_r) % 4 || (uintptr_t)c % 16 || (uintptr_t)yc % 16) return CMF_EINVAL;
+  if (!c || !z || !y || !zi || !si || !ti || n_mod <= 0 || B <= 0 || nc <= 0 || nc % 4) return CMF_EINVAL;
+  if ((c_b | c_r) % 4 || (uintptr_t)c % 16 || (yc && ((yc_b | yc_r) % 4 || (uintptr_t)yc % 16))) return CMF_EINVAL;
   const long long total = (long long)B * n_mod * (nc / 4);
   hipLaunchKernelGGL(acl_cotangent_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, c, c_b, c_r, yc, yc_b,
                      yc_r, nc / 4, z, z_b, y, y_b, g, zi, si, ti, n_mod, total);
@@ -437,8 +449,8 @@ int cmf_acl_cross_terms(const float* c, long long c_b, long long c_r, const floa
                         const float* yt, long long yt_b, long long yt_r, int nc, const float* z, long long z_b,
                         const float* y, long long y_b, const float* g, const int* zi, const int* si, const int* ti,
                         int n_mod, int B, float* dz, float* dy, float* dg, void* stream) {
-  if (!c || !v || !yt || !z || !y || !zi || !si || !ti || !dz || !dy || n_mod <= 0 || B <= 0 || nc <= 0) return CMF_EINVAL;
-  if ((g == nullptr) != (dg == nullptr)) return CMF_EINVAL;
+  if (!c || !v || !z || !y || !zi || !si || !ti || !dy || n_mod <= 0 || B <= 0 || nc <= 0) return CMF_EINVAL;
+  if (yt && (!dz || (g == nullptr) != (dg == nullptr))) return CMF_EINVAL;      // yt null: only dy is written
   const long long n_rows = (long long)B * n_mod;
   hipLaunchKernelGGL(acl_cross_terms_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, c, c_b, c_r, v, v_b, v_r,
                      yt, yt_b, yt_r, nc, z, z_b, y, y_b, g, zi, si, ti, n_mod, n_rows, dz, dy, dg);

@@ -318,6 +318,37 @@ class FlowProgram:
         for m in self.prior:
             if not isinstance(m, (AffineCouplingBijection, AffineBijection, _ReshapingBijection, _PriorFlowLayer)):
                 raise NotImplementedError(f"prior layer {type(m).__name__} is outside the hot path")
+        self.zero_in = self._structural_zeros()
+
+    #: False: every coupling layer runs its whole network whatever it is fed (rounds 1 - 4; the A/B switch of the bit-identity tests)
+    SKIP_STRUCTURAL_ZEROS = True
+
+    def _structural_zeros(self):
+        """Which coupling layers of the DECODE sweep read nothing but structural zeros: {layer index in ``self.layers``: True}.
+        Walks the layer list in decode order with a per-element "known zero" map -- set by ``SplitDensity.pad_inputs``
+        (split.py:26-30,50-52: the dropped half comes back as zeros, primal and every tangent column alike), carried through
+        index maps, cleared on the elements a coupling layer rewrites -- and marks a layer whose network input
+        (``pass_elements``) lies wholly inside it.  Static: derived from the layer list, never from data (no host sync).
+        The image schemas (schemas.py:399-412 reversed) hit it once: 4 checkerboard couplers -> zero-pad -> a split-channel
+        coupler with reverse_mask=True, whose pass-through is the SECOND half of the channels (acl.py:148-160,169-189)."""
+        out = {}
+        zero = np.zeros(int(np.prod(self.tail.x_shape)), dtype=bool)       # the tail's scatter pattern is data (a buffer): unused
+        for i in reversed(range(len(self.layers))):
+            m = self.layers[i]
+            if isinstance(m, AffineCouplingBijection):
+                assert zero.size == m.geom.N
+                if m.net.kind == "resnet" and bool(zero[m.pass_elements()].all()):
+                    out[i] = True
+                zero[m._maps._host["zi"]] = False
+            elif isinstance(m, SplitDensity):
+                zero = np.concatenate((zero, np.ones_like(zero)))
+            elif isinstance(m, _ReshapingBijection) and "z2x" in m._maps._host:
+                zero = zero[m._maps._host["z2x"]]               # x[r] = z[z2x[r]]
+            # (ViewBijection: a contiguous view, the flat map is unchanged)
+        return out
+
+    def _zero(self, i):
+        return self.SKIP_STRUCTURAL_ZEROS and self.zero_in.get(i, False)
 
     # -- per-sample tangent footprint, for sub-batching ------------------------------------------
     def tangent_bytes_per_sample(self, nc):
@@ -428,6 +459,9 @@ class FlowProgram:
                 node = {"elbo": acc.view(B, 1), "low-dim-x": payload, "prior-dict": node}
         return z_low, low_elbo, u, node
 
+    def _decode_order(self):
+        return [(i, self.layers[i]) for i in reversed(range(len(self.layers)))]
+
     # -- z_low -> (x_hat, J) ----------------------------------------------------------------------
     @_scoped
     def decode(self, z_low, tangents=True, eps=None):
@@ -439,9 +473,9 @@ class FlowProgram:
         if tangents:
             ncols = self.d if eps is None else eps.shape[2]
             T = E.seed_tangent(B, N, E.ceil16(ncols), self.layout, scatter, self.d, dev, eps=eps)
-        for m in reversed(self.layers):
+        for i, m in self._decode_order():
             if isinstance(m, AffineCouplingBijection):
-                m.decode_(z, T, ncols=ncols)
+                m.decode_(z, T, ncols=ncols, zero_in=self._zero(i))
             elif isinstance(m, SplitDensity):
                 n = z[0].numel()                 # zero-pad the dropped half (split.py:50-52)
                 idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),
@@ -464,9 +498,9 @@ class FlowProgram:
         N = int(np.prod(self.tail.x_shape))
         z = E.gather_primal(z_low.contiguous(), self.tail.scatter_index(dev), N).view(B, *self.tail.x_shape)
         ctx = []
-        for m in reversed(self.layers):
+        for i, m in self._decode_order():
             if isinstance(m, AffineCouplingBijection):
-                ctx.append(m.decode_ctx_(z))
+                ctx.append(m.decode_ctx_(z, zero_in=self._zero(i)))
             elif isinstance(m, SplitDensity):
                 n = z[0].numel()
                 idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),
@@ -503,9 +537,9 @@ class FlowProgram:
         assert nc % 16 == 0 and nc >= ncols
         T = E.seed_tangent(B, N, nc, self.layout, scatter, self.d, dev, eps=eps) if tangents else None
         ctx = []
-        for m in reversed(self.layers):
+        for i, m in self._decode_order():
             if isinstance(m, AffineCouplingBijection):
-                ctx.append(m.decode_train_(z, T, keep, nc_hint=nc_hint))
+                ctx.append(m.decode_train_(z, T, keep, nc_hint=nc_hint, zero_in=self._zero(i)))
             elif isinstance(m, SplitDensity):
                 n = z[0].numel()
                 idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),
@@ -529,9 +563,9 @@ class FlowProgram:
         nc = E.ceil16(ncols) if nc is None else int(nc)
         T = E.seed_tangent(B, N, nc, self.layout, self.tail.scatter_index(dev), self.d, dev, eps=eps)
         out = []
-        for m, c in zip(reversed(self.layers), ctx):
+        for (i, m), c in zip(self._decode_order(), ctx):
             if isinstance(m, AffineCouplingBijection):
-                out.append(m.decode_tangent_from_ctx_(c, T, save))
+                out.append(m.decode_tangent_from_ctx_(c, T, save, zero_in=self._zero(i)))
             elif isinstance(m, SplitDensity):
                 n = c
                 idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev), torch.full((n,), -1, dtype=torch.int32, device=dev)))

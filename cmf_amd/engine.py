@@ -374,12 +374,15 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     inplace = res_t is not None and res_t.data_ptr() == y_t.data_ptr() and int(res_off) == int(y_off)
     precision = precision or cfg().tangent
     split = (precision == "bf16x3" and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
+             and not (bias is not None and cout > 64)
              and ((fmode != F_NONE and fo is None) or
                   (fmode == F_NONE and (fo is None or (obits and (res_t is None or inplace) and cout % 64 == 0)))))
     # fp16 split kernel: the primal pass's forward form (the input's own relu) or its backward form (plain cotangent in, per-column
     # relu' of a float activation laid out like y on the way out, optional residual: net_primal_backward)
     pbwd = fmode == F_NONE and fo is not None and not obits and fomode == F_SELF_RELU
+    # (the split kernels fetch their per-channel constants once per launch: a bias only with a single 64-channel group)
     f16 = (precision == "f16x3" and cout % 64 == 0 and _shape_ok_bf16x3(taps, cin, W, transpose, H, cout)
+           and not (bias is not None and cout > 64)
            and ((fmode == F_SELF_RELU and fo is None and not transpose) or (pbwd and bias is None and mask_out is None)))
     assert not obits or split, "bit-mask output factors are applied by the split-precision kernel only"
     if obits:
@@ -531,34 +534,50 @@ def seed_tangent(B, N, nc, layout, col_of, d, device, eps=None):
     return T
 
 
+def _y_rows(y, B):
+    """(y as (rows, n), sample stride) of a network output: a one-row ``y`` is SHARED by all B samples (stride 0) -- the output of a
+    coupler network whose input is structurally zero is the same for every sample (``net_primal_zero_input``)."""
+    y2 = y.view(y.shape[0], -1)
+    assert y.shape[0] in (1, B)
+    return y2, (0 if y.shape[0] == 1 and B > 1 else y2.shape[1])
+
+
+def _t3(T):
+    return (None, 0, 0) if T is None else (_p(T.data), T.t_b, T.t_r)
+
+
 def acl_primal(z, y, maps, decode, lj=None):
     B = z.shape[0]
-    z2, y2 = z.view(B, -1), y.view(B, -1)
-    _lib.check(_lib.load().cmf_acl_primal(_p(z2), z2.shape[1], _p(y2), y2.shape[1], _p(maps["zi"]), _p(maps["si"]),
+    z2 = z.view(B, -1)
+    y2, y_b = _y_rows(y, B)
+    _lib.check(_lib.load().cmf_acl_primal(_p(z2), z2.shape[1], _p(y2), y_b, _p(maps["zi"]), _p(maps["si"]),
                                           _p(maps["ti"]), maps["n"], B, int(decode), _p(lj), _stream()), "cmf_acl_primal")
 
 
 def acl_tangent(T, YT, z, y, g, maps):
+    """``YT`` None: the network's tangent is identically zero (structurally-zero network input): T_mod <- e^{-s} T_mod."""
     B = z.shape[0]
-    z2, y2 = z.view(B, -1), y.view(B, -1)
-    launch = lambda: _lib.check(_lib.load().cmf_acl_tangent(_p(T.data), T.t_b, T.t_r, _p(YT.data), YT.t_b, YT.t_r, T.nc, _p(z2),
-                                                            z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]), _p(maps["si"]),
+    z2 = z.view(B, -1)
+    y2, y_b = _y_rows(y, B)
+    launch = lambda: _lib.check(_lib.load().cmf_acl_tangent(_p(T.data), T.t_b, T.t_r, *_t3(YT), T.nc, _p(z2),
+                                                            z2.shape[1], _p(y2), y_b, _p(g), _p(maps["zi"]), _p(maps["si"]),
                                                             _p(maps["ti"]), maps["n"], B, _stream()), "cmf_acl_tangent")
     TIMER = _timer()
     if TIMER is None:
         return launch()
     # coupling pass, per modified element: tangent rows v, s-dot, t-dot in (3 x NC floats), one row out, 5 scalars
     n = float(maps["n"]) * B
-    TIMER.wrap("acl_tangent", 4.0 * n * T.nc, 4.0 * n * (4 * T.nc + 5), launch)
+    TIMER.wrap("acl_tangent", 4.0 * n * T.nc, 4.0 * n * ((4 if YT is not None else 2) * T.nc + 5), launch)
 
 
 def acl_cotangent(Ct, YC, z, y, g, maps):
     """Adjoint of acl_tangent on the cotangent tensor ``Ct`` (in place on the modified rows); fills the modified rows of
-    ``YC`` (cotangent of the coupler network's raw output; the caller zeroed it)."""
+    ``YC`` (cotangent of the coupler network's raw output; the caller zeroed it; None: not wanted)."""
     B = z.shape[0]
-    z2, y2 = z.view(B, -1), y.view(B, -1)
-    _lib.check(_lib.load().cmf_acl_cotangent(_p(Ct.data), Ct.t_b, Ct.t_r, _p(YC.data), YC.t_b, YC.t_r, Ct.nc, _p(z2),
-                                             z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]), _p(maps["si"]),
+    z2 = z.view(B, -1)
+    y2, y_b = _y_rows(y, B)
+    _lib.check(_lib.load().cmf_acl_cotangent(_p(Ct.data), Ct.t_b, Ct.t_r, *_t3(YC), Ct.nc, _p(z2),
+                                             z2.shape[1], _p(y2), y_b, _p(g), _p(maps["zi"]), _p(maps["si"]),
                                              _p(maps["ti"]), maps["n"], B, _stream()), "cmf_acl_cotangent")
 
 
@@ -586,7 +605,8 @@ def acl_cross_terms(Ct, V, YT, z, y, g, maps, dz, dy, dg):
     ``acl_cotangent``.  ``V`` = ``modified_rows(T, maps)`` taken before ``acl_tangent``, ``YT`` = the network's raw tangent."""
     B = z.shape[0]
     z2, y2 = z.view(B, -1), y.view(B, -1)
-    _lib.check(_lib.load().cmf_acl_cross_terms(_p(Ct.data), Ct.t_b, Ct.t_r, _p(V.data), V.t_b, V.t_r, _p(YT.data), YT.t_b, YT.t_r,
+    # YT None (network tangent identically zero): only the log-scale entries of dy receive a term; dz / dg are not touched
+    _lib.check(_lib.load().cmf_acl_cross_terms(_p(Ct.data), Ct.t_b, Ct.t_r, _p(V.data), V.t_b, V.t_r, *_t3(YT),
                                                Ct.nc, _p(z2), z2.shape[1], _p(y2), y2.shape[1], _p(g), _p(maps["zi"]),
                                                _p(maps["si"]), _p(maps["ti"]), maps["n"], B, _p(dz), _p(dy), _p(dg), _stream()),
                "cmf_acl_cross_terms")
@@ -1083,6 +1103,23 @@ def net_primal(net, z, view, need_acts=True):
     return h, None, acts
 
 
+def net_primal_zero_input(net, view, B, device):
+    """(y, g), one row each, of a coupler network whose input is structurally ZERO -- the channels ``SplitDensity.pad_inputs``
+    appended (split.py:50-52) feeding a coupler that passes exactly those through (acl.py:148-160): the output is the same for
+    every sample, so ONE sample group runs (16 zero samples where the batch takes the sample-grouped kernels, 1 otherwise: the
+    same kernels, hence the same bits, as the full batch) and the coupling kernels read it with sample stride 0.  Cached per
+    parameter version and KernelConfig."""
+    rows = 16 if B % 16 == 0 else 1
+    params = list(net.parameters())
+
+    def build():
+        z0 = torch.zeros(rows, *view.geom.shape, dtype=torch.float32, device=device)
+        y, g, _ = net_primal(net, z0, view, need_acts=False)
+        return y[:1].clone(), (None if g is None else g[:1].clone())
+
+    return DERIVED.get((id(params[0]), "zero-input", rows, cfg().primal, str(device)), params, build)
+
+
 class GroupedActs(list):
     """Primal activations kept as (B/16, C, H, W, 16): 16 samples in the 16 column slots of the tangent kernels
     (supported as a factor source through ``f_group``, but slower to read than the standard layout)."""
@@ -1134,8 +1171,10 @@ def _resnet_primal_grouped(net, blocks, convf, a0, B, hid, cout, H, W, need_acts
     new = lambda: torch.empty(G * hid * HW * 16, dtype=torch.float32, device=dev)
     train = need_acts == "train"                          # ActList: the "bits" form + the grouped floats
     prec = cfg().primal
-    if prec == "f16x3" and hid % 64:
-        prec = "f32"                                      # the fp16 split kernel works on whole 64-channel groups
+    if (prec == "f16x3" and hid % 64) or (prec in ("f16x3", "bf16x3") and hid > 64):
+        # the split kernels work on whole 64-channel groups and fetch the bias of ONE group per launch (cmf_conv_tangent_f16x3
+        # returns CMF_EINVAL for a bias with cout > 64): wider networks (g_hidden_channels 128, 192, ...) take the fp32 kernel
+        prec = "f32"
     bits = (need_acts == "bits" or train) and prec != "bf16x3" and hid % 16 == 0
     a = primal_regroup(a0, True)
     acts, masks = [a], []

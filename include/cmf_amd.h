@@ -220,10 +220,14 @@ int cmf_acl_primal(float* z, long long z_b, const float* y, long long y_b, const
                    const int* ti, int n_mod, int B, int decode, float* lj, void* stream);
 /* tangent: T(b, zi[e], :) = exp(-s) * (T(b, zi[e], :) - z_old * sdot) - tdot   (acl.py:61-64, :137-144)
  *   sdot = gs * yt(b, si[e], :), tdot = gt * yt(b, ti[e], :), gs/gt = g(b, si[e]) / g(b, ti[e]) or 1 when
- *   g == NULL; z_old = z(b, zi[e]) BEFORE cmf_acl_primal decode is applied; s from y.              */
+ *   g == NULL; z_old = z(b, zi[e]) BEFORE cmf_acl_primal decode is applied; s from y.
+ * yt == NULL: the network's tangent is identically zero (its pass-through input is structurally zero, e.g. the channels
+ *   SplitDensity.pad_inputs appended, split.py:50-52): T(b, zi[e], :) *= exp(-s).
+ * y_b == 0 (here and in cmf_acl_primal): one network output shared by every sample (same situation: the input is zero).  */
 /* cotangent (adjoint of cmf_acl_tangent, for J^T w / the reverse sweep): with c = C(b, zi[e], :) on entry,
  *   yc(b, ti[e], :) = -gt * c,   yc(b, si[e], :) = -(exp(-s) * z_old * gs) * c,   C(b, zi[e], :) = exp(-s) * c.
- * yc rows that no element maps to must be zero (the caller clears yc).                              */
+ * yc rows that no element maps to must be zero (the caller clears yc).
+ * yc == NULL: only C is updated (the cotangent of the network's input lands on rows that are dropped).   */
 int cmf_acl_cotangent(float* c, long long c_b, long long c_r, float* yc, long long yc_b, long long yc_r, int nc,
                       const float* z, long long z_b, const float* y, long long y_b, const float* g, const int* zi,
                       const int* si, const int* ti, int n_mod, int B, void* stream);
@@ -241,7 +245,8 @@ int cmf_acl_primal_backward(float* dx, long long dx_b, const float* z, long long
  * cotangent c of `out` (rows zi[e], BEFORE cmf_acl_cotangent rewrites them), the saved input rows v (compact: row e at
  * v + b*v_b + e*v_r) and the network's raw tangent yt, accumulates (+=) the column reductions
  *   dy[b][si[e]] += d/ds,   dz[b][zi[e]] += d/d zo,   dg[b][si[e]] += d/d gs,   dg[b][ti[e]] += d/d gt
- * (dg and g both NULL for networks without the ScaledTanh output stage).                                     */
+ * (dg and g both NULL for networks without the ScaledTanh output stage).
+ * yt == NULL (network tangent identically zero): only dy[b][si[e]] -= sum_col c es v is accumulated; dz, dg unused.  */
 int cmf_acl_cross_terms(const float* c, long long c_b, long long c_r, const float* v, long long v_b, long long v_r,
                         const float* yt, long long yt_b, long long yt_r, int nc, const float* z, long long z_b,
                         const float* y, long long y_b, const float* g, const int* zi, const int* si, const int* ti,

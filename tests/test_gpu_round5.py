@@ -1,0 +1,215 @@
+"""Round-5 GPU tests: structural zeros in the decode sweep (the coupler fed by ``SplitDensity.pad_inputs``' zero channels runs no
+tangent network and evaluates its primal network once), against the full computation -- bit for bit -- and the fixtures.
+Every call goes through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_gpu_parity import build, find_head, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(g, n, seed=11):
+    """n distinct head inputs around the fixture's (the fixtures hold 2 - 3 samples)."""
+    x0 = g["head_input"].float() if "head_input" in g else g["x"].float()
+    gen = torch.Generator().manual_seed(seed)
+    x = x0[torch.randint(0, x0.shape[0], (n,), generator=gen)]
+    return (x + 0.01 * torch.randn(x.shape, generator=gen)).cuda()
+
+
+class _full:
+    """``with _full(prog):`` -- every coupling layer runs its whole network (rounds 1 - 4)."""
+
+    def __init__(self, prog):
+        self.prog = prog
+
+    def __enter__(self):
+        self.prog.SKIP_STRUCTURAL_ZEROS = False
+
+    def __exit__(self, *exc):
+        del self.prog.SKIP_STRUCTURAL_ZEROS
+        return False
+
+
+@pytest.mark.parametrize("name,B", [("mini_mnist", 3), ("mini_mnist", 32), ("mini_cifar", 3), ("mini_cifar", 16), ("c3_mnist_full", 2),
+                                    ("c3_mnist_full", 32), ("c5_cifar_full", 16)])
+def test_structural_zero_coupler_is_skipped_bit_for_bit(name, B):
+    """x_hat, J, J^T J, log-det, g_ij, elbo and J^T w of the skipping decode sweep == the full one's, ``torch.equal``; the tangent
+    network of exactly one coupler does not run (16 hidden launches fewer for the 8-block networks)."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    prog = head.program
+    assert len(prog.zero_in) == 1
+    x = _batch(g, B)
+    out = {}
+    with torch.no_grad():
+        z_low = prog.encode(x)[0]
+        Wd = torch.randn(B, int(np.prod(head.x_shape)), 3, device="cuda")
+        for mode in ("skip", "full"):
+            ctx = _full(prog) if mode == "full" else torch.no_grad()
+            with ctx, E.timing(lambda n: n.startswith("conv_tangent")) as timer:
+                x_hat, T = prog.decode(z_low, tangents=True)
+                gr = E.gram_cholesky(T, prog.d)
+                elbo = head.elbo(x.clone(), add_offdiagonal_metric_reg=True)["elbo"]
+                xv, jw = prog.vjp(z_low, Wd)
+                x_dec, _ = prog.decode(z_low, tangents=False)
+                launches = {k: v[0] for k, v in timer.by_name().items()}
+            out[mode] = dict(x_hat=x_hat.clone(), J=T.to_dense(prog.d).clone(), jtj=gr.jtj.clone(), logdet=gr.logdet.clone(),
+                             l1=gr.l1_off.clone(), elbo=elbo.clone(), jw=jw.clone(), xv=xv.clone(), x_dec=x_dec.clone(), launches=launches)
+    a, b = out["skip"], out["full"]
+    for k in ("x_hat", "J", "jtj", "logdet", "l1", "elbo", "jw", "xv", "x_dec"):
+        assert torch.equal(a[k], b[k]), (name, B, k, rel(a[k], b[k]))
+    # the skipped coupler's hidden tangent convs: 2 per residual block, in each of the two tangent sweeps (decode, elbo) and in the
+    # reverse sweep (vjp)
+    net = prog.layers[next(iter(prog.zero_in))].net
+    blocks = sum(1 for m in net.module if hasattr(m, "conv1"))
+    hid = net.module[0].out_channels
+    key = f"conv_tangent_t9_ci{hid}_co{hid}"
+    assert b["launches"][key] - a["launches"][key] == 3 * (2 * blocks), (a["launches"], b["launches"])
+
+
+@pytest.mark.parametrize("name,B,kw", [
+    ("mini_mnist", 3, dict(add_offdiagonal_metric_reg=True)),
+    ("mini_mnist", 32, dict(add_diagonal_metric_reg=True)),
+    ("mini_cifar", 16, dict(add_offdiagonal_metric_reg=True)),
+    ("c3_mnist_full", 32, dict(add_offdiagonal_metric_reg=True)),
+])
+def test_structural_zero_skip_gives_the_same_gradients(name, B, kw):
+    """Training step with the skip == without: identical elbo, and every gradient tensor identical (``torch.equal``) where the
+    full computation itself repeats bit for bit, else within twice its own run-to-run spread (atomic accumulation order).  Also
+    with recomputation per coupling layer."""
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    prog = head.program
+    x = _batch(g, B)
+    with _full(prog):
+        loss_f, elbo_f, grads_f = head.loss_and_gradients(x.clone(), **kw)
+        loss_f2, elbo_f2, grads_f2 = head.loss_and_gradients(x.clone(), **kw)
+    loss_s, elbo_s, grads_s = head.loss_and_gradients(x.clone(), **kw)
+    head.recompute = True
+    loss_r, elbo_r, grads_r = head.loss_and_gradients(x.clone(), **kw)
+    head.recompute = None
+    assert torch.equal(elbo_s, elbo_f) and torch.equal(elbo_r, elbo_f) and set(grads_s) == set(grads_f) == set(grads_r)
+    exact = 0
+    for p in grads_f:
+        spread = rel(grads_f2[p], grads_f[p])
+        if spread == 0.0:
+            assert torch.equal(grads_s[p], grads_f[p]), (name, tuple(p.shape), rel(grads_s[p], grads_f[p]))
+            exact += 1
+        else:
+            assert rel(grads_s[p], grads_f[p]) <= 2 * spread, (name, tuple(p.shape), rel(grads_s[p], grads_f[p]), spread)
+        assert rel(grads_r[p], grads_f[p]) < 1e-6
+    assert exact > 0
+
+
+def test_structural_zero_skip_in_the_lowrank_hutchinson_training_step():
+    """Train-mode ``hutch_with_cg`` on the full-size CIFAR model (S = 4: the low-rank backward, two tangent sweeps over one primal
+    decode): same surrogate value and gradients with and without the skip."""
+    g, meta, cfg, dens = build("c5_cifar_full")
+    head = find_head(dens)
+    prog = head.program
+    head.log_jacobian_method, head.num_hutchinson_samples = "hutch_with_cg", 4
+    head.train()
+    x = _batch(g, 32)
+    outs = []
+    for mode in ("full", "skip"):
+        torch.manual_seed(0)                                                # the same probes
+        if mode == "full":
+            with _full(prog):
+                outs.append(head.loss_and_gradients(x.clone()))
+        else:
+            outs.append(head.loss_and_gradients(x.clone()))
+        assert head.last_hutchinson.get("lowrank") is not None
+    (lf, ef, gf), (ls, es, gs) = outs
+    assert torch.equal(ef, es) and set(gf) == set(gs)
+    for p in gf:
+        assert rel(gs[p], gf[p]) < 1e-6, (tuple(p.shape), rel(gs[p], gf[p]))
+
+
+def test_coupling_kernels_with_a_null_network_tangent_and_a_shared_network_output():
+    """cmf_acl_tangent / cmf_acl_cotangent / cmf_acl_cross_terms with yt = NULL == the same call on an all-zero yt; cmf_acl_primal /
+    cmf_acl_tangent with y_b = 0 == the same call on the row repeated B times."""
+    from cmf_amd import engine as E
+    from cmf_amd.bijections import SplitChannelwiseAffineCouplingBijection
+    from cmf_amd.densities import FlowProgram  # noqa: F401
+    gen = torch.Generator().manual_seed(2)
+    B, C, H, W, nc = 5, 4, 6, 6, 16
+    N = C * H * W
+
+    class _Coupler(torch.nn.Module):
+        shift_log_scale_net = None
+    acl = SplitChannelwiseAffineCouplingBijection((C, H, W), lambda n: _Coupler(), reverse_mask=True)
+    maps = acl.maps("cuda")
+    z = torch.randn(B, C, H, W, generator=gen).cuda()
+    y1 = (0.3 * torch.randn(1, 2 * acl.cmod, H, W, generator=gen)).cuda()
+    g1 = torch.rand(1, 2 * acl.cmod, H, W, generator=gen).cuda()
+    yB, gB = y1.expand(B, -1, -1, -1).contiguous(), g1.expand(B, -1, -1, -1).contiguous()
+    T0 = torch.randn(B * N * nc, generator=gen).cuda()
+    mk = lambda: E.Tangent(B, N, nc, "panel", "cuda", data=T0.clone())
+    YT0 = E.Tangent(B, yB[0].numel(), nc, "panel", "cuda")
+    YT0.data.zero_()
+    # tangent update
+    Ta, Tb, Tc = mk(), mk(), mk()
+    E.acl_tangent(Ta, YT0, z, yB, gB, maps)
+    E.acl_tangent(Tb, None, z, yB, gB, maps)
+    E.acl_tangent(Tc, None, z, y1, g1, maps)
+    assert torch.equal(Ta.data, Tb.data) and torch.equal(Ta.data, Tc.data)
+    # primal update with a shared row
+    za, zb = z.clone(), z.clone()
+    E.acl_primal(za, yB, maps, decode=True)
+    E.acl_primal(zb, y1, maps, decode=True)
+    assert torch.equal(za, zb)
+    lja, ljb = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+    za, zb = z.clone(), z.clone()
+    E.acl_primal(za, yB, maps, decode=True, lj=lja)
+    E.acl_primal(zb, y1, maps, decode=True, lj=ljb)
+    assert torch.equal(za, zb) and torch.equal(lja, ljb)
+    # adjoint
+    Ca, Cb = mk(), mk()
+    YC = E.Tangent(B, yB[0].numel(), nc, "panel", "cuda")
+    YC.data.zero_()
+    E.acl_cotangent(Ca, YC, z, yB, gB, maps)
+    E.acl_cotangent(Cb, None, z, y1, g1, maps)
+    assert torch.equal(Ca.data, Cb.data)
+    # cross terms
+    V = E.modified_rows(mk(), maps)
+    dza, dya, dga = torch.zeros_like(z), torch.zeros_like(yB), torch.zeros_like(gB)
+    dyb, dgb = torch.zeros_like(yB), torch.zeros_like(gB)
+    Ct = mk()
+    E.acl_cross_terms(Ct, V, YT0, z, yB, gB, maps, dza, dya, dga)
+    E.acl_cross_terms(Ct, V, None, z, yB, gB, maps, None, dyb, dgb)
+    assert torch.equal(dya, dyb) and float(dza.abs().max()) == 0.0 and float(dga.abs().max()) == 0.0 and float(dgb.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("hidden,B", [(128, 16), (128, 3), (192, 16)])
+def test_wide_resnet_couplers_under_the_default_kernel_config(hidden, B):
+    """g_hidden_channels of 128 / 192: the fp16-split primal kernel fetches ONE 64-channel group's bias per launch and
+    refuses wider layers, so the sample-grouped primal pass must fall back to the fp32 kernel there -- elbo against the oracle,
+    eval and one training step's gradients against the oracle's autograd."""
+    import cmf_amd
+    from cmf_amd.recipe import fill_state_dict
+    from oracle import cmf_oracle as O
+    cfg = cmf_amd.get_config("mnist", g_hidden_channels=[hidden], latent_dimension=8, log_jacobian_method="cholesky")
+    schema = cmf_amd.get_schema(cfg)
+    gen = torch.Generator().manual_seed(hidden + B)
+    x = torch.randint(0, 256, (B, 1, 28, 28), generator=gen).float() + torch.rand(B, 1, 28, 28, generator=gen)
+    density = cmf_amd.get_density(schema, x)
+    sd = fill_state_dict(density.state_dict(), seed=0)
+    density.load_state_dict(sd)
+    density = density.cuda().eval()
+    inner = density.module.density
+    with torch.no_grad():
+        got = inner.elbo(x.cuda(), add_reconstruction=True, add_offdiagonal_metric_reg=True)["elbo"]
+        ops = O.compile_schema(schema, (1, 28, 28))
+        want = O.elbo(sd, ops, x, add_offdiagonal_metric_reg=True, noise=torch.zeros_like(x))["elbo"]
+    assert rel(got, want) < 1e-4
+    head = find_head(density)
+    pre, _, flow_ops, base, prior_ops = O.split_ops(ops)
+    with torch.no_grad():
+        y, pre_lj = O.prehead(pre, x, noise=torch.zeros_like(x))
+    loss, elbo, grads = head.loss_and_gradients(y.cuda(), add_offdiagonal_metric_reg=True)
+    assert rel(elbo, want - pre_lj.view(-1, 1)) < 1e-4
+    assert all(torch.isfinite(v).all() for v in grads.values())

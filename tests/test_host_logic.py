@@ -254,3 +254,50 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     ck.load_checkpoint(str(tmp_path), "latest", c, [opt_c], [torch.optim.lr_scheduler.StepLR(opt_c, 5)])
     assert all(torch.equal(v, c.state_dict()[k]) for k, v in a.state_dict().items())
     assert math.isinf(ck.write_checkpoint.__defaults__[-2])
+
+
+@pytest.mark.parametrize("name", ["mini_mnist", "mini_cifar", "c2b_hepmass", "c1_sphere"])
+def test_structural_zero_plan_matches_the_oracles_data(name):
+    """``FlowProgram.zero_in`` (a static walk over the layer list) marks exactly the coupling layers whose network input the
+    ORACLE finds identically zero -- primal and every tangent column -- in a decode sweep from a random latent: the coupler
+    right behind ``SplitDensity.pad_inputs`` (split.py:50-52) whose pass-through half is the padded one (acl.py:148-160)."""
+    from cmf_amd.bijections import AffineCouplingBijection, SplitChannelwiseAffineCouplingBijection
+    from cmf_amd.densities import SplitDensity
+    g, meta = load_golden(name)
+    dens = cmf_amd.get_density(cmf_amd.get_schema(cmf_amd.get_config(meta["dataset"], **meta["overrides"])), g["x"])
+    prog = _find(dens, "NonSquareHeadDensity").program
+    _, _, _, ops, sd = golden_model(meta)
+    _, _, flow_ops, base, _ = O.split_ops(ops)
+    gen = torch.Generator().manual_seed(3)
+    d = base["d"]
+    z = torch.randn(2, d, generator=gen)
+    h, hv = O.tail_scatter(sd, base, z), O.tail_scatter(sd, base, torch.eye(d).expand(2, d, d))
+    zero_ops = []                                             # position among the acl ops, decode order
+    k = 0
+    with torch.no_grad():
+        for op in reversed(flow_ops):
+            if op["kind"] == "acl":
+                if op["mask_type"] == "checkerboard":
+                    m = sd[op["prefix"] + "mask"]
+                    net_in, net_v = m * h, m * hv
+                else:
+                    net_in, net_v = O._cw_split(op, h)[0], O._cw_split(op, hv, 2)[0]
+                if float(net_in.abs().max()) == 0.0 and float(net_v.abs().max()) == 0.0:
+                    zero_ops.append(k)
+                k += 1
+                h, hv = O.acl_jvp_multi(sd, op, h, hv)
+            elif op["kind"] == "flatten":
+                h, hv = h.reshape(h.shape[0], *op["x_shape"]), hv.reshape(*hv.shape[:2], *op["x_shape"])
+            elif op["kind"] == "squeeze":
+                h, hv = O.squeeze_z_to_x(h, op["factor"]), O.squeeze_z_to_x(hv, op["factor"])
+            elif op["kind"] == "split":
+                h, hv = torch.cat((h, torch.zeros_like(h)), 1), torch.cat((hv, torch.zeros_like(hv)), 2)
+    order = [i for i, _ in prog._decode_order()]
+    acl_pos = {i: n for n, i in enumerate(i for i in order if isinstance(prog.layers[i], AffineCouplingBijection))}
+    assert sorted(acl_pos[i] for i in prog.zero_in) == zero_ops
+    if name.startswith("mini"):                               # image schemas (schemas.py:399-412): exactly one, right behind the pad
+        (i,) = prog.zero_in
+        assert isinstance(prog.layers[i], SplitChannelwiseAffineCouplingBijection) and prog.layers[i].reverse_mask
+        assert isinstance(prog.layers[i + 1], SplitDensity)   # decode order runs the list backwards
+    else:
+        assert not prog.zero_in
