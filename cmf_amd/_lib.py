@@ -28,7 +28,7 @@ class ConvTangentArgs(C.Structure):
                 ("np", _i), ("cin", _i), ("cout", _i), ("H", _i), ("W", _i), ("nc", _i), ("taps", _i),
                 ("bias", _fp), ("f_group", _i), ("x_sl", _ll), ("y_sl", _ll), ("r_sl", _ll),
                 ("fo", _fp), ("fo_np", _ll), ("fo_co", _ll), ("fo_px", _ll), ("fomode", _i),
-                ("mask_out", _fp), ("mask_np", _ll), ("amax_in", _fp), ("amax_out", _fp)]
+                ("mask_out", _fp), ("mask_np", _ll), ("amax_in", _fp), ("amax_out", _fp), ("live", _i)]
 
 
 class ConvPrimalArgs(C.Structure):

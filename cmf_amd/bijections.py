@@ -160,8 +160,17 @@ class AffineCouplingBijection(Bijection):
         y, g, acts = E.net_primal(self.net, z, view, need_acts=want)
         if T is not None:
             YT = E.net_tangent(self.net, T, view, acts)
-            E.acl_tangent(T, YT, z, y, g, self.maps(z.device))      # uses z BEFORE the primal update
+            self._acl_tangent(T, YT, z, y, g)                       # uses z BEFORE the primal update
         E.acl_primal(z, y, self.maps(z.device), decode=True, lj=lj)
+
+    def _acl_tangent(self, T, YT, z, y, g):
+        if getattr(YT, "compact", False):
+            # checkerboard tail (engine.net_tangent): the network's tangent exists at the modified pixels only, stored compactly;
+            # (s, g) are read through the same compact index maps
+            cm = self.compact_maps(z.device)
+            yc, gc = E.gather_primal(y, cm["y_idx"], cm["y_n"]), E.gather_primal(g, cm["y_idx"], cm["y_n"])
+            return E.acl_tangent(T, YT, z, yc, gc, cm)
+        E.acl_tangent(T, YT, z, y, g, self.maps(z.device))
 
     # reverse sweep (J^T w): primal decode that keeps what the adjoint needs, then the adjoint step ------------
     def decode_ctx_(self, z, zero_in=False):
@@ -228,7 +237,7 @@ class AffineCouplingBijection(Bijection):
         else:
             saved = [] if save else None
             YT = E.net_tangent(self.net, T, view, acts, save=saved)
-        E.acl_tangent(T, YT, zb, y, g, maps)                 # zb: the layer input, i.e. z BEFORE the primal update
+        self._acl_tangent(T, YT, zb, y, g)                   # zb: the layer input, i.e. z BEFORE the primal update
         return (zb, y, g, acts, saved, V, YT) if save else None
 
     def decode_backward_(self, Ct, dx, ctx, grads):
@@ -322,9 +331,35 @@ class Checkerboard2dAffineCouplingBijection(AffineCouplingBijection):
         zi = np.flatnonzero(mask.reshape(-1) == 0)
         self._set_maps(zi, zi, cmod=C)          # the net sees all C channels: its output is indexed like z
         self._pass_elements = np.flatnonzero(mask.reshape(-1) != 0)
+        # compact form of the network's output (engine.net_tangent: last hidden conv and 1x1 conv at the modified pixels only):
+        # pixel (row, col) of the (1 - mask) set sits at row * W/2 + col // 2
+        self._live = None
+        if W % 2 == 0:
+            HW, HWc = H * W, H * W // 2
+            livepix = np.flatnonzero(m.reshape(-1) == 0)                      # row-major = compact order (W/2 per row)
+            assert len(livepix) == HWc and (livepix // W * (W // 2) + livepix % W // 2 == np.arange(HWc)).all()
+            cidx = np.full(HW, -1)
+            cidx[livepix] = np.arange(HWc)
+            ch, px = zi // HW, zi % HW
+            self._maps.put("c_ti", ch * HWc + cidx[px])
+            self._maps.put("c_si", (C + ch) * HWc + cidx[px])
+            self._maps.put("c_y_idx", (np.arange(2 * C)[:, None] * HW + livepix[None, :]).reshape(-1))
+            self._live = 2 if reverse_mask else 1                            # the modified pixels' (row + col) % 2 + 1
+            self._livepix = livepix
 
     def view(self, device):
-        return E.NetView(self.geom, cin=self.geom.C, mask=self.mask)
+        live = None
+        if self._live is not None and self.net.kind == "resnet":
+            hid = self.net.module[0].out_channels
+            key = f"c_act_idx_{hid}"
+            if key not in self._maps._host:
+                self._maps.put(key, (np.arange(hid)[:, None] * self.geom.HW + self._livepix[None, :]).reshape(-1))
+            live = {"parity": self._live, "act_idx": self._maps.get(key, device)}
+        return E.NetView(self.geom, cin=self.geom.C, mask=self.mask, live=live)
+
+    def compact_maps(self, device):
+        return {"zi": self._maps.get("zi", device), "si": self._maps.get("c_si", device), "ti": self._maps.get("c_ti", device),
+                "n": self.n_mod, "y_idx": self._maps.get("c_y_idx", device), "y_n": 2 * self.geom.C * (self.geom.HW // 2)}
 
     def pass_elements(self):
         return self._pass_elements                           # the net reads mask . z (acl.py:48-52)

@@ -467,7 +467,7 @@ extern "C" int cmf_conv_tangent(const cmf_conv_tangent_args* ap, void* stream) {
   const cmf_conv_tangent_args& a = *ap;
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
   if (a.taps != 1 && a.taps != 9) return CMF_EINVAL;
-  if (a.nc <= 0 || a.nc % 16) return CMF_EINVAL;
+  if (a.nc <= 0 || a.nc % 16 || a.live) return CMF_EINVAL;     // checkerboard output: cmf_conv_tangent_bf16x3 only
   if (a.fmode < CMF_F_NONE || a.fmode > CMF_F_SELF_RELU) return CMF_EINVAL;
   if (a.fmode != CMF_F_NONE && a.fmode != CMF_F_SELF_RELU && !a.f) return CMF_EINVAL;
   // 16-byte vector loads of the column slices

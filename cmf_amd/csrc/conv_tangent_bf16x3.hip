@@ -154,9 +154,15 @@ __device__ __forceinline__ int xslot(int col, int pix) { return (((col & 3) << 2
 // (measured: median g_ij error of the full-size model 1.3e-6 against 4e-7).  The accumulators start at zero, the item's last chunk
 // carries no tail, and after it the wave loads the residual into the registers its fragments occupied and adds it ONCE, after the
 // products, like cmf_conv_tangent does.  The round trip is exposed once per item: ~15 % on the 80 launches of a step that have one.
-template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false>
+// CKB (a.live = 1 / 2, forward tangent conv with relu' factor): CHECKERBOARD output -- only the pixels with (row + col) % 2 == live - 1 are
+// computed: the last hidden conv of a checkerboard coupler's network is read, through the pointwise 1x1 conv, at the (1 - mask)
+// pixels alone (acl.py:48-66).  The staging (loader waves, LDS images, centre ring) is the full tile's; an MFMA wave owns the LIVE
+// pixels of its rows -- every second one, the phase alternating from row to row: C::PW / 2 accumulator pixels, half the MFMAs and
+// B-fragment reads -- loads the residual at those pixels of the FULL image and stores into the COMPACT one (row*(W/2) + col/2).
+template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false, bool CKB = false>
 __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_tangent_args a, int tiles_x, int ntiles,
                                                                        int nslices, int ncog, int total) {
+  static_assert(!CKB || (!F16 && !FRES && (MODE == 1 || MODE == 3)), "checkerboard output: the forward tangent conv with a relu' factor");
   static_assert(!F16 || ((MODE == 2 || MODE == 4) && (COT == 4 || COT == 2)), "the fp16 variant is the primal pass: SELF mode (forward) or 4 (backward)");
   // BWD (F16 with MODE 4): the primal BACKWARD's data-gradient convs -- plain input (a cotangent, no relu on load), the packed
   // adjoint operator, and  y = [fo > 0] . conv(x) + r  with fo a float tensor laid out like y (the forward activation whose relu
@@ -181,7 +187,11 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   constexpr bool NOF = SELF || PLAIN || BWD;                     // no factor stream
   constexpr int NF = NOF ? 0 : BITS ? 1 : 8;                     // factor loads per loader thread and chunk
   using C = BCfg<COT, PXW>;
-  constexpr int CW = COT / 2, PW = C::PW;
+  // PW = accumulator pixels of an MFMA wave; tp(p) = the p-th one's pixel inside the wave's C::PW tile pixels (CKB: the even ones;
+  // the row's phase o is added through per-lane / scalar offsets below), trow(p) = its row within the wave's rows
+  constexpr int CW = COT / 2, PW = CKB ? C::PW / 2 : C::PW;
+  auto tp = [](int p) constexpr { return CKB ? 2 * p : p; };
+  auto trow = [&](int p) constexpr { return tp(p) / C::TW; };
   static_assert(COT % 2 == 0, "the co-split wave layout needs an even number of output-channel tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages x [Xh | Xl | Wh | Wl]
 
@@ -607,6 +617,23 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     coff_ring[par] = 2 * C::BUF_BYTES + (kq < 3 ? kq : 0) * C::RING_SLOT + wrow * C::TW * 256 + sl;
     coff_stage[par] = cpix * 256 + sl;
   }
+  // CKB: the live pixels of the wave's row k are tile pixels 2 j + o_k, o_k = (live - 1 + wrow + k) & 1 (tile origins are even in both
+  // directions).  The phase only moves the pixel by one slot of 256 B and flips the slot permutation's parity: folded into the
+  // per-lane offsets, indexed by the row's parity k & 1 instead of the pixel's
+  [[maybe_unused]] const int ck_o[2] = {(a.live - 1 + wrow) & 1, (a.live + wrow) & 1};
+  if constexpr (CKB) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int b0 = boff[s][0], b1 = boff[s][1];
+      boff[s][0] = ck_o[0] ? b1 + 256 : b0;
+      boff[s][1] = ck_o[1] ? b1 + 256 : b0;
+    }
+    const int r0 = coff_ring[0], r1 = coff_ring[1], s0 = coff_stage[0], s1 = coff_stage[1];
+    coff_ring[0] = ck_o[0] ? r1 + 256 : r0;
+    coff_ring[1] = ck_o[1] ? r1 + 256 : r0;
+    coff_stage[0] = ck_o[0] ? s1 + 256 : s0;
+    coff_stage[1] = ck_o[1] ? s1 + 256 : s0;
+  }
   const int aoff = (lane << 4) + ((cohalf * CW * 64) << 4);
 
   // Fragment pipeline: step t = s*PW + p consumes B fragment pair t; pairs are fetched BD-1 steps ahead into a ring
@@ -615,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #ifdef CMF_DBG_BD
   constexpr int BD = CMF_DBG_BD;
 #else
-  constexpr int BD = C::PW > 14 ? 3 : 4;                           // 16-pixel waves (4 x 8 tiles): 128 accumulator VGPRs, shallower ring
+  constexpr int BD = PW > 14 ? 3 : 4;                           // 16-pixel waves (4 x 8 tiles): 128 accumulator VGPRs, shallower ring
 #endif
 
   // Item context.  The launcher guarantees whole tiles (H even, W % TW == 0) and whole channel groups, so the tail has
@@ -636,7 +663,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     int tile;
     decode(item, tile, slice, cog, np);
     const int pix0 = (C::TH * (tile / tiles_x) + wrow) * a.W + C::TW * (tile % tiles_x);
-    it.ypix = 4 * pix0 * y_px;
+    it.ypix = CKB ? 4 * ((C::TH * (tile / tiles_x) + wrow) * (a.W / 2) + C::TW / 2 * (tile % tiles_x)) * y_px    // compact image
+                  : 4 * pix0 * y_px;
     it.rpix = 4 * pix0 * r_px;
     it.pix0 = pix0, it.np = np, it.cog = cog;
   };
@@ -721,7 +749,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
     for (int i = 0; i < 4; ++i) rrs[i] = __builtin_amdgcn_readfirstlane(rrs_in[i]);
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-      const int so = it.rpix + 4 * (((p / C::TW) * a.W + p % C::TW) * r_px + c * 16 * r_co);
+      const int so = it.rpix + 4 * ((trow(p) * a.W + tp(p) % C::TW + (CKB ? ck_o[trow(p) & 1] : 0)) * r_px + c * 16 * r_co);
       asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(acc[p][c]) : "v"(rvoff), "s"(rrs), "s"(so) : "memory");
     }
   };
@@ -777,7 +805,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       else v += bias[c];                                           // per-channel constant (primal bias)
       if constexpr (FRES) v += c == 0 ? radd0 : radd1;             // the residual, once, after the products
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, v), cur_yrs, vo,
-                                             it.ypix + 4 * (((p / C::TW) * a.W + p % C::TW) * y_px + c * 16 * y_co), 0);
+                                             it.ypix + 4 * ((CKB ? trow(p) * (a.W / 2) + tp(p) % C::TW / 2 : (p / C::TW) * a.W + p % C::TW) * y_px +
+                                                            c * 16 * y_co), 0);
       if constexpr (F16) {
         vst[c] = v;
         // inline asm on purpose (also the mask code below): written with builtins (fmaxf, __ballot + selects) this epilogue sent
@@ -892,12 +921,13 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
       asm volatile("" : "=v"(bh[t % BD]), "=v"(bl[t % BD]));
       return;
 #endif
+      const int q = tp(p), par = CKB ? trow(p) & 1 : p & 1;        // CKB: offsets indexed by the row's parity (phase folded in)
       if (s < 2) {
-        bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][p & 1] + C::pl(p) * 256);
-        bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][p & 1] + C::pl(p) * 256);
+        bh[t % BD] = *reinterpret_cast<const bf16x8*>(Xh + boff[s][par] + C::pl(q) * 256);
+        bl[t % BD] = *reinterpret_cast<const bf16x8*>(Xl + boff[s][par] + C::pl(q) * 256);
       } else {                                     // ring rows are TW pixels long, stage rows TWH: per-lane row step
-        bh[t % BD] = *reinterpret_cast<const bf16x8*>(ch_[p & 1] + p * 256 + (p / C::TW) * crow);
-        bl[t % BD] = *reinterpret_cast<const bf16x8*>(cl_[p & 1] + p * 256 + (p / C::TW) * crow);
+        bh[t % BD] = *reinterpret_cast<const bf16x8*>(ch_[par] + q * 256 + (q / C::TW) * crow);
+        bl[t % BD] = *reinterpret_cast<const bf16x8*>(cl_[par] + q * 256 + (q / C::TW) * crow);
       }
     };
 #pragma unroll
@@ -920,7 +950,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int u = lane + 64 * k;
-        if (u < PW * 16) cp[k] = *reinterpret_cast<const u32x4*>(src + u * 16 + ((u >> 4) / C::TW) * (C::TWH - C::TW) * 256);
+        if (u < C::PW * 16) cp[k] = *reinterpret_cast<const u32x4*>(src + u * 16 + ((u >> 4) / C::TW) * (C::TWH - C::TW) * 256);
       }
     }
 #endif
@@ -937,7 +967,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int u = lane + 64 * k;
-          if (u < PW * 16) *reinterpret_cast<u32x4*>(dst + u * 16) = cp[k];
+          if (u < C::PW * 16) *reinterpret_cast<u32x4*>(dst + u * 16) = cp[k];
         }
       }
 #endif
@@ -1166,14 +1196,14 @@ __global__ __launch_bounds__(1024) void pack_f16_scale_kernel(const float* __res
   }
 }
 
-template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false>
+template <int COT, int PXW, int MODE, bool F16 = false, bool FRES = false, bool CKB = false>
 int launch(const cmf_conv_tangent_args& a, hipStream_t s) {
   using C = BCfg<COT, PXW>;
   const int tiles_x = cmf_ceil_div(a.W, C::TW), tiles = tiles_x * cmf_ceil_div(a.H, C::TH);
   const int nslices = a.nc / 16, ncog = (F16 && COT == 2) ? a.cout / 32 : cmf_ceil_div(a.cout, 64);
   const long long total = (long long)tiles * nslices * ncog * a.np;
   if (total > 0x7fffffffLL) return CMF_ERANGE;
-  auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE, F16, FRES>;
+  auto k = conv_tangent_bf16x3_kernel<COT, PXW, MODE, F16, FRES, CKB>;
   constexpr int lds = C::LDS_BYTES;
   if (hipError_t e = cmf_set_dynamic_lds((const void*)k, lds); e != hipSuccess) return (int)e;   // per device (runtime.hip)
   const int n_cu = cmf_device_cus();
@@ -1267,6 +1297,13 @@ extern "C" int cmf_conv_tangent_bf16x3(const cmf_conv_tangent_args* ap, void* st
   const bool t14 = a.W % 14 == 0 && a.H % 2 == 0, t8 = a.W % 8 == 0 && a.H % 4 == 0;
   if (!(t14 || t8) || !(a.cout % 64 == 0 || a.cout == 32)) return CMF_EINVAL;
   if (a.bias && a.cout > 64) return CMF_EINVAL;                 // the per-channel constants are fetched once per launch
+  if (a.live) {
+    // checkerboard output: the forward tangent conv with a relu' factor, whole 64-channel groups, nothing in the epilogue but the residual
+    if (a.live < 0 || a.live > 2 || (a.fmode != CMF_F_RELU && a.fmode != CMF_F_RELU_BITS) || a.fo || a.bias || a.cout % 64 || a.W % 2)
+      return CMF_EINVAL;
+    if (a.fmode == CMF_F_RELU) return t14 ? launch<4, 7, 1, false, false, true>(a, s) : launch<4, 4, 1, false, false, true>(a, s);
+    return t14 ? launch<4, 7, 3, false, false, true>(a, s) : launch<4, 4, 3, false, false, true>(a, s);
+  }
   if (a.fmode == CMF_F_NONE && !a.fo) {
     // the PLAIN kernel fetches its output mask unconditionally: without one, let it read (and ignore) the first bytes of
     // every sample's input tensor -- H*W*cout/8 bytes per sample, always inside x (cin*nc*4 >= 2 KiB per pixel)
@@ -1287,7 +1324,7 @@ extern "C" int cmf_conv_tangent_f16x3_item(const cmf_conv_tangent_args* ap, int 
   if (!ap || (item_channels != 0 && item_channels != 32 && item_channels != 64)) return CMF_EINVAL;
   const cmf_conv_tangent_args& a = *ap;
   if (!a.x || !a.w || !a.y || a.np <= 0 || a.cin <= 0 || a.cout <= 0 || a.H <= 0 || a.W <= 0) return CMF_EINVAL;
-  if (a.taps != 9 || a.cin % 32 || a.nc <= 0 || a.nc % 16 || a.cout % 64) return CMF_EINVAL;
+  if (a.taps != 9 || a.cin % 32 || a.nc <= 0 || a.nc % 16 || a.cout % 64 || a.live) return CMF_EINVAL;
   // forward: the input's own relu, no output factor.  backward (data gradient): plain input, the adjoint pack, y = [fo > 0] . conv
   // + r with fo a float tensor laid out like y (fomode CMF_F_SELF_RELU: cmf_conv_tangent's primal-backward form), no bias, no sign bits
   const bool bwd = a.fmode == CMF_F_NONE && a.fo && a.fomode == CMF_F_SELF_RELU;

@@ -359,10 +359,12 @@ def conv_primal(x_ptr_t, x_off, x_b, x_c, x_px, weight, taps, bias, y, y_b, y_c,
 def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_px, np_, cin, cout, H, W, nc,
                  fmode=F_NONE, f=None, f_np=0, f_ci=0, f_px=0, res_t=None, transpose=False, bias=None, f_group=1,
                  x_sl=16, y_sl=16, precision=None, y_off=0, res_off=0, fo=None, fo_np=0, fo_co=0, fo_px=0, fomode=F_NONE,
-                 mask_out=None, mask_np=0, amax_in=None, amax_out=None, item_channels=0):
+                 mask_out=None, mask_np=0, amax_in=None, amax_out=None, item_channels=0, live=0, res_np=None):
     """``fo`` = OUTPUT-side factor (reverse sweep, fp32 kernel only); ``y_off`` / ``res_off`` = element offsets into
     ``y_t`` / ``res_t`` (in-place accumulation into a strided view of a larger tensor).  ``precision`` "f16x3": the fp16 split
-    kernel of the primal pass (``amax_in`` / ``amax_out``: one-float device tensors, the input-range chain)."""
+    kernel of the primal pass (``amax_in`` / ``amax_out``: one-float device tensors, the input-range chain).  ``live`` 1 / 2:
+    checkerboard output (split-precision kernel only): the pixels with (row + col) % 2 == live - 1, stored compactly
+    (``res_np``: sample stride of the residual, a FULL image then; the other residual strides are y's)."""
     lib = _lib.load()
     a = ConvTangentArgs()
     a.x = C.c_void_p(x_t.data_ptr() + 4 * int(x_off)); a.x_np, a.x_ci, a.x_px = int(x_np), int(x_ci), int(x_px)
@@ -390,12 +392,14 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
     a.w = _p(PACKS.get(weight, taps, transpose, bf16x3="f16x3" if f16 else split))
     a.y = C.c_void_p(y_t.data_ptr() + 4 * int(y_off)); a.y_np, a.y_co, a.y_px = int(y_np), int(y_co), int(y_px)
     a.r = None if res_t is None else C.c_void_p(res_t.data_ptr() + 4 * int(res_off))
-    a.r_np, a.r_co, a.r_px = int(y_np), int(y_co), int(y_px)
+    a.r_np, a.r_co, a.r_px = int(y_np if res_np is None else res_np), int(y_co), int(y_px)
     a.fo = _p(fo); a.fo_np, a.fo_co, a.fo_px, a.fomode = int(fo_np), int(fo_co), int(fo_px), int(fomode)
     a.mask_out = _p(mask_out); a.mask_np = int(mask_np)
     assert not (fmode == F_RELU_BITS and not split), "bit-mask factors are read by the split-precision kernel only"
     assert not (mask_out is not None and split), "sign bits are written by the fp32 and the fp16-split kernels only"
     a.amax_in, a.amax_out = (_p(amax_in), _p(amax_out)) if f16 else (None, None)
+    a.live = int(live)
+    assert not live or split, "checkerboard output is the split-precision kernel's"
     a.np, a.cin, a.cout, a.H, a.W, a.nc, a.taps = int(np_), int(cin), int(cout), int(H), int(W), int(nc), int(taps)
     a.bias = _p(bias); a.f_group = int(f_group)
     a.x_sl, a.y_sl, a.r_sl = int(x_sl), int(y_sl), int(y_sl)
@@ -415,8 +419,8 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
         return launch()
     # algorithmic work of this launch: 2*cin*cout*taps FLOP per output pixel and Jacobian column; every input,
     # output and residual element crosses HBM once (4 bytes each)
-    px = float(H) * W * nc * np_
-    TIMER.wrap(f"conv_tangent_t{taps}_ci{cin}_co{cout}" + ("_primal" if fmode == F_SELF_RELU else "_primal_bwd" if pbwd else ""),
+    px = float(H) * W * nc * np_ * (0.5 if live else 1.0)
+    TIMER.wrap(f"conv_tangent_t{taps}_ci{cin}_co{cout}" + ("_primal" if fmode == F_SELF_RELU else "_primal_bwd" if pbwd else "_live" if live else ""),
                2.0 * cin * cout * taps * px,
                4.0 * px * (cin + cout + (cout if res_t is not None else 0)), launch)
 
@@ -1032,8 +1036,11 @@ def elbo_combine(low, logdet, rec, l1, pre, wl, lam, wm, B, device):
 class NetView:
     """Where a coupler network reads its input inside the current primal / tangent tensors."""
 
-    def __init__(self, geom, cin, chan_off=0, chan_step=1, mask=None):
+    def __init__(self, geom, cin, chan_off=0, chan_step=1, mask=None, live=None):
         self.geom, self.cin, self.chan_off, self.chan_step, self.mask = geom, cin, chan_off, chan_step, mask
+        #: checkerboard couplers: {"parity": 1 | 2, "act_idx": int32 map (hid * HW/2,) gathering the live pixels of a (hid, H, W)
+        #: activation} -- the network's output is read at the pixels with (row + col) % 2 == parity - 1 only (net_tangent)
+        self.live = live
 
 
 class Geometry:
@@ -1232,11 +1239,19 @@ def _view_rows(T, view):
     return out
 
 
+#: checkerboard couplers: last hidden conv and 1x1 conv at the (1 - mask) pixels only (False: every pixel, rounds 1 - 4)
+CHECKERBOARD_TAIL = True
+
+
 def net_tangent(net, T, view, acts, transpose_packs=False, save=None):
     """Push all Jacobian columns of ``T`` through the coupler network; returns the raw tangent of the
     network's pre-activation output (the ScaledTanh derivative ``g`` is applied by acl_tangent).
     ``save`` (a list, training): the input tangent of every conv / linear layer is kept and appended, in forward order
-    (the network's own input as a compact copy of the rows it reads), for ``net_cotangent(..., saved=, grads=)``."""
+    (the network's own input as a compact copy of the rows it reads), for ``net_cotangent(..., saved=, grads=)``.
+    Checkerboard couplers (``view.live``, evaluation only): a checkerboard layer reads (s, t, s-dot, t-dot) at its (1 - mask)
+    pixels alone (acl.py:48-66) and the network's last layer is a pointwise 1x1 conv, so the LAST hidden conv (with its residual
+    read) and the 1x1 conv run on those pixels only; the returned stack is then COMPACT -- (B, cout * HW/2, nc), pixel (row, col)
+    at row * W/2 + col // 2 -- and carries ``compact = True`` (``AffineCouplingBijection.decode_`` switches index maps)."""
     geo, B, nc, dev = view.geom, T.B, T.nc, T.data.device
     if save is not None:
         save.append(_view_rows(T, view))
@@ -1260,9 +1275,23 @@ def net_tangent(net, T, view, acts, transpose_packs=False, save=None):
         # relu' source of a hidden conv: float activations, or the bit mask the primal pass wrote (BitMask)
         fk = lambda t: dict(fmode=F_RELU_BITS, f=t.data, f_np=t.np_bytes) if isinstance(t, BitMask) else dict(fmode=F_RELU, f=t, **fs)
         u, h2 = new(hid), new(hid)
+        compact = (CHECKERBOARD_TAIL and view.live is not None and save is None and fg == 1 and len(blocks) > 0 and hid % 64 == 0
+                   and W % 2 == 0 and _use_bf16x3(9, hid, W, False, H, hid))
         for k, blk in enumerate(blocks):
             a_in, c1 = acts[2 * k], acts[2 * k + 1]
             conv_tangent(h.data, 0, *hd, blk.conv1.weight, 9, u.data, *hd, B, hid, hid, H, W, nc, x_sl=hsl, y_sl=hsl, **fk(a_in))
+            if compact and k + 1 == len(blocks):
+                # the last hidden conv at the live pixels only, stored compactly; its residual read at those pixels of the full h
+                HWc = HW // 2
+                hc = Tangent(B, hid * HWc, nc, "panel", dev)
+                conv_tangent(u.data, 0, *hd, blk.conv2.weight, 9, hc.data, hid * HWc * nc, 16, hid * nc, B, hid, hid, H, W, nc,
+                             res_t=h.data, res_np=hd[0], x_sl=hsl, y_sl=hsl, live=view.live["parity"], **fk(c1))
+                a_last = gather_primal(acts[-1], view.live["act_idx"], hid * HWc)         # relu' source of the 1x1 conv, compact too
+                yt = Tangent(B, cout * HWc, nc, "panel", dev)
+                conv_tangent(hc.data, 0, hid * HWc * nc, 16, hid * nc, convf.weight, 1, yt.data, cout * HWc * nc, HWc * nc, nc, B, hid,
+                             cout, H, W // 2, nc, fmode=F_RELU, f=a_last, x_sl=hsl, f_np=hid * HWc, f_ci=HWc, f_px=1)
+                yt.compact = True
+                return yt
             conv_tangent(u.data, 0, *hd, blk.conv2.weight, 9, h2.data, *hd, B, hid, hid, H, W, nc, res_t=h.data, x_sl=hsl,
                          y_sl=hsl, **fk(c1))
             if save is not None:                              # keep h_k and u_k: no ping-pong reuse

@@ -112,6 +112,13 @@ typedef struct {
                                                    input overflows fp16 and small ones keep their low half.  amax_out: one device float,
                                                    atomically raised to max(y) over the stored values (the caller zeroes it: the next
                                                    conv's amax_in, whose relu-on-load ignores negative values); NULL = off              */
+  int live;                                     /* cmf_conv_tangent_bf16x3 only, fmode RELU / RELU_BITS, whole 64-channel groups, no bias / fo:
+                                                   CHECKERBOARD output.  0 = every pixel.  1 / 2: only the pixels with (row + col) % 2 ==
+                                                   live - 1 are computed -- the (1 - mask) pixels of Checkerboard2dAffineCouplingBijection
+                                                   (acl.py:48-66, :68-78), all a coupler network's LAST hidden conv is ever read at, since the
+                                                   1x1 conv behind it is pointwise -- and y is COMPACT: pixel (row, col) is stored at pixel
+                                                   index row*(W/2) + col/2 (y_px = stride between compact pixels).  x, f and the residual r
+                                                   keep the full H x W image; r is read at the live pixels.                              */
 } cmf_conv_tangent_args;
 /* (A launch with taps == 9, cin <= 2, cout % 64 == 0, no residual / bias / output factor / mask_out and fmode NONE or RAW -- the
  * first conv of a coupler network, networks.py:40-47 -- is an HBM write stream and runs on a VALU kernel instead of the MFMA one:

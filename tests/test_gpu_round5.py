@@ -213,3 +213,70 @@ def test_wide_resnet_couplers_under_the_default_kernel_config(hidden, B):
     loss, elbo, grads = head.loss_and_gradients(y.cuda(), add_offdiagonal_metric_reg=True)
     assert rel(elbo, want - pre_lj.view(-1, 1)) < 1e-4
     assert all(torch.isfinite(v).all() for v in grads.values())
+
+
+@pytest.mark.parametrize("H,W", [(14, 14), (28, 28), (16, 16), (32, 32), (4, 14), (8, 8)])
+@pytest.mark.parametrize("live", [1, 2])
+@pytest.mark.parametrize("fmode", ["relu", "bits"])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_checkerboard_output_of_the_split_kernel(H, W, live, fmode, with_res):
+    """cmf_conv_tangent_bf16x3 with ``live`` = 1 / 2 (the last hidden conv of a checkerboard coupler's network, acl.py:48-66): the
+    compact output == the full launch's at the pixels with (row + col) % 2 == live - 1, bit for bit, and == F.conv2d x mask in
+    float64 to the split arithmetic's accuracy; the residual is read at those pixels of the full image."""
+    import torch.nn.functional as F
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(H * 100 + W + live)
+    B, C, nc, HW = 3, 64, 32, H * W
+    S = nc // 16
+    x = torch.randn(B, C, H, W, nc, generator=gen)
+    prim = torch.randn(B, C, H, W, generator=gen)
+    res = torch.randn(B, C, H, W, nc, generator=gen)
+    w = torch.randn(C, C, 3, 3, generator=gen) / 24
+    to_dev = lambda t: t.reshape(B, C, -1, S, 16).permute(0, 2, 3, 1, 4).contiguous().cuda()     # slice-major [px][slice][ch][16]
+    st, sl = (C * HW * nc, 16, C * nc), C * 16
+    wd = torch.nn.Parameter(w.cuda())
+    xd, rd = to_dev(x), to_dev(res) if with_res else None
+    bits = E.relu_bits(prim.cuda())
+    fk = dict(fmode=E.F_RELU_BITS, f=bits.data, f_np=bits.np_bytes) if fmode == "bits" else dict(fmode=E.F_RELU, f=prim.cuda(), f_np=C * HW, f_ci=HW, f_px=1)
+    full = torch.empty(B, HW, S, C, 16, device="cuda")
+    E.conv_tangent(xd, 0, *st, wd, 9, full, *st, B, C, C, H, W, nc, res_t=rd, x_sl=sl, y_sl=sl, precision="bf16x3", **fk)
+    comp = torch.full((B, HW // 2, S, C, 16), float("nan"), device="cuda")
+    E.conv_tangent(xd, 0, *st, wd, 9, comp, st[0] // 2, st[1], st[2], B, C, C, H, W, nc, res_t=rd, x_sl=sl, y_sl=sl, precision="bf16x3",
+                   live=live, res_np=st[0], **fk)
+    ii, jj = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    sel = ((ii + jj) % 2 == live - 1).reshape(-1)                       # row-major order of the live pixels = the compact index
+    assert int(sel.sum()) == HW // 2
+    assert torch.equal(comp, full[:, sel.cuda()])
+    want = F.conv2d((x * (prim > 0).float().unsqueeze(-1)).permute(0, 4, 1, 2, 3).reshape(B * nc, C, H, W).double(), w.double(), padding=1)
+    want = want.reshape(B, nc, C, HW).permute(0, 3, 1, 2).reshape(B, HW, S, 16, C).permute(0, 1, 2, 4, 3)
+    if with_res:
+        want = want + to_dev(res).cpu().double()
+    assert rel(comp, want[:, sel]) < 2e-5
+
+
+@pytest.mark.parametrize("name,B", [("c3_mnist_full", 2), ("c3_mnist_full", 32), ("c5_cifar_full", 16), ("c3_mnist_full_cond", 2)])
+def test_checkerboard_tail_of_the_coupler_networks_is_bit_identical(name, B, monkeypatch):
+    """The seven checkerboard couplers' last hidden conv + 1x1 conv at the (1 - mask) pixels only (engine.net_tangent, compact
+    output) against the full-image form: x_hat, J, J^T J, log-det, g_ij and elbo ``torch.equal``; 7 launches take the
+    checkerboard form per tangent sweep."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    prog = head.program
+    x = _batch(g, B)
+    out = {}
+    with torch.no_grad():
+        z_low = prog.encode(x)[0]
+        for mode in (True, False):
+            monkeypatch.setattr(E, "CHECKERBOARD_TAIL", mode)
+            with E.timing(lambda n: n.startswith("conv_tangent")) as timer:
+                x_hat, T = prog.decode(z_low, tangents=True)
+                gr = E.gram_cholesky(T, prog.d)
+                launches = {k: v[0] for k, v in timer.by_name().items()}
+            elbo = head.elbo(x.clone(), add_offdiagonal_metric_reg=True)["elbo"]
+            out[mode] = dict(x_hat=x_hat.clone(), J=T.to_dense(prog.d).clone(), jtj=gr.jtj.clone(), logdet=gr.logdet.clone(), l1=gr.l1_off.clone(),
+                             elbo=elbo.clone(), launches=launches)
+    for k in ("x_hat", "J", "jtj", "logdet", "l1", "elbo"):
+        assert torch.equal(out[True][k], out[False][k]), (name, B, k, rel(out[True][k], out[False][k]))
+    assert out[True]["launches"].get("conv_tangent_t9_ci64_co64_live") == 7 and "conv_tangent_t9_ci64_co64_live" not in out[False]["launches"]
+    assert out[False]["launches"]["conv_tangent_t9_ci64_co64"] - out[True]["launches"]["conv_tangent_t9_ci64_co64"] == 7
