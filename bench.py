@@ -50,6 +50,8 @@ CONFIGS = {
     "c5": ("cifar10", {"latent_dimension": 128, "hutchinson_samples": 4}, 32, False,
            "C5: CIFAR-shaped (3,32,32) D=3072 d=128, 32 samples per GPU (256 over 8)"),
 }
+#: SURVEY 8d, "Algorithmic work per eval (dense; the figure roofline.achieved uses)": W_alg = (2 + d) F_net + F_prior + 2 D d^2 + d^3/3, FLOP / sample
+W_ALG_FLOP = {"c1": 7.3e3, "c2a": 4.0e6, "c2b": 12.8e6, "c3": 290.42e9, "c5": 749.67e9}
 METRICS = {
     "c1": "log-density evals/sec (JtJ-cholesky path), sphere D=3 d=3 bs=1024",
     "c2a": "log-density evals/sec (JtJ-cholesky path), tabular D=6 d=2 bs=4096",
@@ -233,14 +235,25 @@ def cpu_baseline(schema, shape, sd, B_cpu, dataset, off, label):
     # oversubscribed OpenMP teams crawl, so size the pool to the affinity mask capped at that share
     cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("CMF_CPU_THREADS", 16))))
     torch.set_num_threads(cores)
-    print(f"[bench] cpu_baseline: oracle ref-equivalent, B={B_cpu}, {cores} threads ...", file=sys.stderr, flush=True)
+    # SURVEY 8d / BASELINE.md section 3: one untimed warm-up call (thread pool, oneDNN primitive caches, page faults), then the cost
+    # at B_cpu / 4, B_cpu / 2, B_cpu (C3: 8, 16, 32 -- linear in B); `value` is the largest sample's rate
+    sizes = [B_cpu] if B_cpu < 8 else [B_cpu // 4, B_cpu // 2, B_cpu]
+    warm = 0 if B_cpu < 8 else max(1, sizes[0] // 2)
+    print(f"[bench] cpu_baseline: oracle ref-equivalent, warm-up B={warm}, timed B={sizes}, {cores} threads ...", file=sys.stderr, flush=True)
+    run = lambda n: O.elbo(sd, ops, x[:n], add_offdiagonal_metric_reg=off, noise=None if noise is None else noise[:n], flavour="ref_equivalent")
+    per_b = {}
     with torch.no_grad():
-        t0 = time.perf_counter()
-        O.elbo(sd, ops, x, add_offdiagonal_metric_reg=off, noise=noise, flavour="ref_equivalent")
-        dt = time.perf_counter() - t0
+        if warm:
+            run(warm)
+        for n in sizes:
+            t0 = time.perf_counter()
+            run(n)
+            per_b[n] = time.perf_counter() - t0
+    dt = per_b[B_cpu]
     return {"value": B_cpu / dt, "unit": "evals/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
-            "sample": f"B={B_cpu}, {label}, one elbo call, {dt:.1f} s, "
-                      f"oracle.jtj_ref_equivalent (column loop + primal recompute = what the reference executes)"}
+            "evals_per_s_by_batch": {str(n): n / t for n, t in per_b.items()}, "warmup_batch": warm,
+            "sample": f"B={B_cpu}, {label}, one elbo call after a warm-up call at B={warm}, {dt:.1f} s ({sum(per_b.values()):.0f} s for "
+                      f"B = {sizes}), oracle.jtj_ref_equivalent (column loop + primal recompute = what the reference executes)"}
 
 
 def cpu_model():
@@ -455,7 +468,8 @@ def roofline_of(name, n, ms, flops, nbytes, step_ms_total, precision, B, pmc=Tru
                 # context, not the contract's peak: what a loop of nothing but this MFMA sustains on live random operands on every
                 # SIMD (tools/ubench/mfmapower.py, profiles/r03_mfma_sustained.txt: the chip lowers its clock under the load)
                 "live_data_mfma_ceiling": {"frac_of_peak": 0.72, "frac_of_ceiling": 3.0 * tf / BF16_MFMA_PEAK_TFLOPS / 0.72,
-                                           "source": "profiles/r03_mfma_sustained.txt (tools/ubench/mfmapower.py; measured once per round, not by this run)"},
+                                           "source": "profiles/r04_mfma_sustained.txt (tools/ubench/mfmapower.py, 16x16x32 bf16, changing random "
+                                                     "operands, 2 waves / SIMD; measured once per round, not by this run)"},
                 "hbm_view": {"algorithmic_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}, **common}
     if name.startswith("conv_tangent") or name.startswith("mlp_") or name == "gram_cholesky":
         traffic, note = pmc_traffic("f32", B) if (name == "conv_tangent_t9_ci64_co64" and pmc) else (None, None)
@@ -464,6 +478,35 @@ def roofline_of(name, n, ms, flops, nbytes, step_ms_total, precision, B, pmc=Tru
                 "hbm_view": {"algorithmic_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}, **common}
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
             "kernel": name, **common}
+
+
+def end_to_end(config, evals_per_s, precision, density):
+    """SURVEY 8d "Which roofline -- End-to-end: MFMA": achieved = W_alg x evals/s with the DENSE algorithmic count W_alg (unchanged
+    by the work the decode sweep skips: the structurally-zero coupler's tangent network and the dead checkerboard pixels of the last
+    hidden conv -- ``skipped_of_dense_hidden_convs`` says how much of the dominant stage that is), against the fp32-matrix peak
+    and, with the split-precision tangent convs, against the bf16 peak in bf16 products (3 per fp32-grade product)."""
+    tf = W_ALG_FLOP[config] * evals_per_s / 1e12
+    out = {"W_alg_gflop_per_eval": W_ALG_FLOP[config] / 1e9, "W_alg_tflop_per_s": tf, "count": "dense (SURVEY 8d), not reduced by skipped work",
+           "fp32_matrix": {"achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS}}
+    if precision == "bf16x3" and config in ("c3", "c5"):
+        out.update(achieved=3.0 * tf, peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s (bf16 products, 3 per fp32-grade product)",
+                   frac=3.0 * tf / BF16_MFMA_PEAK_TFLOPS)
+    else:
+        out.update(achieved=tf, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_MFMA_PEAK_TFLOPS)
+    try:
+        from cmf_amd.bijections import AffineCouplingBijection
+        heads = [m for m in density.modules() if type(m).__name__ == "NonSquareHeadDensity"]
+        prog = heads[0].program
+        acls = [m for m in prog.layers if isinstance(m, AffineCouplingBijection) and m.net.kind == "resnet"]
+        if acls:
+            per = [2 * sum(1 for b in m.net.module if hasattr(b, "conv1")) for m in acls]            # hidden convs per coupler
+            zero = {i for i in prog.zero_in}
+            skipped = sum(float(per[k]) if prog._zero(i) else (0.5 if getattr(m, "_live", None) else 0.0)
+                          for k, (i, m) in enumerate((i, m) for i, m in enumerate(prog.layers) if m in acls))
+            out["skipped_of_dense_hidden_convs"] = {"launch_equivalents": skipped, "of": sum(per), "zero_input_couplers": len(zero)}
+    except Exception:                                       # noqa: BLE001 -- a note, never the measurement
+        pass
+    return out
 
 
 def set_kernels(density, tangent=None, primal=None):
@@ -509,16 +552,22 @@ def eval_timed(wl, world, steps, warmup, timer_select=None, graph=None, grouped=
         torch.cuda.synchronize()
 
     import contextlib
+    # per-step durations ("median of >= 10 after 3 warm-ups"): one HIP event on the launch stream after every step, read
+    # after the closing fence -- `value` stays on the total wall time between the fences (the driver's own clock sees that)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     with torch.no_grad():
         for _ in range(warmup):
             step()
         with (E.timing(timer_select) if timer_select is not None else contextlib.nullcontext()) as timer:
             fence()
             t0 = time.perf_counter()
-            for _ in range(steps):
+            marks[0].record()
+            for i in range(steps):
                 loss = step()
+                marks[i + 1].record()
             fence()
             dt = time.perf_counter() - t0
+    wl.step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     rows = timer.by_name() if timer is not None else None
     tmax = torch.tensor([dt], device=wl.device, dtype=torch.float64)
     seen = 1
@@ -603,15 +652,17 @@ def run_rank(args):
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device("cuda", 0 if args.share_gpu else local)
-    torch.cuda.set_device(device)
     if world > 1 or args.force_group:
+        # BEFORE the first torch.cuda call: the HIP / HSA runtime reads its environment when it initialises
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "MASTER_ADDR" not in os.environ:                  # --force-group from a bare shell
             with socket.socket() as s_:
                 s_.bind(("127.0.0.1", 0))
                 free = s_.getsockname()[1]
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    device = torch.device("cuda", 0 if args.share_gpu else local)
+    torch.cuda.set_device(device)
+    if world > 1 or args.force_group:
         init_group(args, world, device)
     grouped = world > 1 or args.force_group
 
@@ -693,6 +744,8 @@ def run_rank(args):
                 return train_leg(args.leg_steps, 1, "c5", wl5.inner, wl5.x, 32, rank, world, device, wl5.off)
             finally:
                 del wl5
+                import gc
+                gc.collect()                                 # (module graphs hold reference cycles: free the C5 model NOW)
                 torch.cuda.empty_cache()
 
         def train():
@@ -729,6 +782,11 @@ def run_rank(args):
             line["roofline"] = roofline_of(name, n, ms, fl, by, step_ms, args.precision, B, pmc=(args.config == "c3"))
             if args.graph:
                 line["roofline"]["note"] = "kernel events from 3 eager steps after the timed graph replays; share_of_step = share of GPU kernel time"
+        med = sorted(wl.step_ms)[len(wl.step_ms) // 2] if len(wl.step_ms) % 2 else \
+            0.5 * (sorted(wl.step_ms)[len(wl.step_ms) // 2 - 1] + sorted(wl.step_ms)[len(wl.step_ms) // 2])
+        line["ms_per_step_median"] = med
+        line["ms_per_step_minmax"] = [min(wl.step_ms), max(wl.step_ms)]
+        line["end_to_end"] = end_to_end(args.config, B * world * args.steps / dt, args.precision, inner)
         if stages is not None:
             line["stages"] = stages
         if args.force_group:

@@ -356,7 +356,11 @@ int launch_cot(const cmf_conv_tangent_args& a, hipStream_t s) {
     case 1: return launch<TAPS, 1, PXW>(a, s);
     case 2: return launch<TAPS, 2, PXW>(a, s);
     case 3: return launch<TAPS, 3, PXW>(a, s);
-    default: return launch<TAPS, 4, PXW>(a, s);
+    default:
+      // 2 x 16 tiles with four channel tiles per wave need 267 VGPRs (hipcc spilled 11 to scratch): there a 64-channel group is
+      // always dealt to two workgroups of 32 channels (the generic-width / CIFAR path of the exact-fp32 kernel; same results)
+      if constexpr (TAPS == 9 && PXW == 8) return launch<TAPS, 2, PXW>(a, s, 2);
+      else return launch<TAPS, 4, PXW>(a, s);
   }
 }
 

@@ -708,7 +708,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   Item cur, nxt;
   int np_, slice_, cog_;
   item_geom(0, np_, slice_, cog_, cur);
-  nxt = cur;
+  nxt.ypix = cur.ypix, nxt.rpix = cur.rpix, nxt.pix0 = cur.pix0, nxt.np = cur.np, nxt.cog = cur.cog;   // (field by field: a struct copy
+                                                                                                        // left a dead 20-byte stack slot)
   // Per-channel constants (primal bias): a bias implies a single channel group (launcher precondition), so they are
   // fetched ONCE per launch -- by inline asm like the residual, so that hipcc never places a vmcnt wait of its own
   // among the hand-counted ones; a NULL bias is a zero-record descriptor (reads 0).  (A per-store
@@ -1031,13 +1032,21 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   __syncthreads();                                                 // stage 0 ready
   for (int item = 0; item < n_items; ++item) {
     const bool has_next = item + 1 < n_items;
-    auto nxt_yrs = cur_yrs;
-    auto nxt_mrs = cur_mrs;
+    [[maybe_unused]] auto nxt_yrs = cur_yrs;
     auto next_context = [&]() __attribute__((always_inline)) {                                   // derived right before the chunk that uses it
       int np, slice, cog;
       item_geom(has_next ? item + 1 : item, np, slice, cog, nxt);
-      nxt_yrs = y_rsrc(np, slice, cog);
-      if constexpr (F16) nxt_mrs = m_rsrc(np, slice, cog);
+      if constexpr (F16) {
+        // fp16 variants: the store descriptors of THIS item are derived here, right before its last chunk, instead of riding
+        // along as a (current, next) pair through every chunk: 16 SGPRs fewer in the steady state (hipcc had left a dead 16-byte
+        // descriptor spill slot + the scavenging slot on the stack of the <2,7,2> form: 20 bytes of scratch that no instruction used)
+        int cnp, cslice, ccog, ctile;
+        decode(item, ctile, cslice, ccog, cnp);
+        cur_yrs = y_rsrc(cnp, cslice, ccog);
+        cur_mrs = m_rsrc(cnp, cslice, ccog);
+      } else {
+        nxt_yrs = y_rsrc(np, slice, cog);
+      }
       nxt_rrs = r_rsrc(np, slice, cog, has_next);                  // last item: zero records, nothing is fetched
     };
     // nchunks = 4 G (launcher precondition): chunks 4m, 4m+1, 4m+2 run two K-steps and park their centre pixels, chunk
@@ -1111,9 +1120,8 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
         }
       }
     }
-    cur = nxt;
-    cur_yrs = nxt_yrs;
-    cur_mrs = nxt_mrs;
+    cur.ypix = nxt.ypix, cur.rpix = nxt.rpix, cur.pix0 = nxt.pix0, cur.np = nxt.np, cur.cog = nxt.cog;
+    if constexpr (!F16) cur_yrs = nxt_yrs;
   }
   STAMP2(0, 11, 0);
   if constexpr (F16) {
@@ -1350,15 +1358,18 @@ extern "C" int cmf_conv_tangent_f16x3_item(const cmf_conv_tangent_args* ap, int 
   // MFMA work is the shorter item
   const int TH = t14 ? 2 : 4, TW = t14 ? 14 : 8;
   const long long items64 = (long long)(a.H / TH) * (a.W / TW) * (a.nc / 16) * (a.cout / 64) * a.np;
-  const bool half = item_channels ? item_channels == 32 : 2 * items64 <= cmf_device_cus();
+  // 4 x 8 tiles (16- / 32-wide images): ALWAYS 32-channel items.  A 64-channel item there is 16 pixels x 2 channel tiles = 128
+  // accumulator VGPRs per wave on top of the fp16 epilogue's state: hipcc needed 263 - 278 registers and spilled 7 - 22 of them to
+  // scratch (round 4); the two sizes give bit-identical results, so the request for 64 is served by two half items.
+  const bool half = !t14 || (item_channels ? item_channels == 32 : 2 * items64 <= cmf_device_cus());
   if (bwd) {
     if (half) return t14 ? launch<2, 7, 4, true, true>(a, s) : launch<2, 4, 4, true, true>(a, s);
-    return t14 ? launch<4, 7, 4, true, true>(a, s) : launch<4, 4, 4, true, true>(a, s);
+    return launch<4, 7, 4, true, true>(a, s);
   }
   if (half) {
     if (a.r) return t14 ? launch<2, 7, 2, true, true>(a, s) : launch<2, 4, 2, true, true>(a, s);
     return t14 ? launch<2, 7, 2, true>(a, s) : launch<2, 4, 2, true>(a, s);
   }
-  if (a.r) return t14 ? launch<4, 7, 2, true, true>(a, s) : launch<4, 4, 2, true, true>(a, s);
-  return t14 ? launch<4, 7, 2, true>(a, s) : launch<4, 4, 2, true>(a, s);
+  if (a.r) return launch<4, 7, 2, true, true>(a, s);
+  return launch<4, 7, 2, true>(a, s);
 }

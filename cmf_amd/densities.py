@@ -274,7 +274,7 @@ def _scoped(fn):
 
     @functools.wraps(fn)
     def run(self, *args, **kwargs):
-        with E.scope(self.head.kernels), E._lib.phase(fn.__name__):
+        with E.scope(self.head.kernels), E._lib.phase(fn.__name__):      # (``head``: a weak proxy, see FlowProgram.__init__)
             return fn(self, *args, **kwargs)
     return run
 
@@ -288,7 +288,10 @@ class FlowProgram:
     TANGENT_BUDGET = 160 << 30                      # of the 288 GB; C3 at B = 512 needs ~20 GB, C5 at B = 256 ~45 GB
 
     def __init__(self, head):
-        self.head = head
+        import weakref
+        # the head owns the program (``head._program``): holding the head strongly here would make a reference cycle, and heads,
+        # parameters and cached buffers would then be freed by the cyclic GC only, not by refcount
+        self.head = weakref.proxy(head)
         self.layers = []
         node = head.prior
         while not isinstance(node, NonSquareTailDensity):

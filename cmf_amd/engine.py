@@ -245,26 +245,56 @@ class _PackCache:
 
     def get(self, weight, taps, transpose=False, bf16x3=False):
         """``bf16x3``: False = cmf_pack_weight's floats, True / "bf16x3" = the split-precision pack, "f16x3" = the fp16 pack
-        (scaled by a power of two, 16-byte trailer)."""
+        (scaled by a power of two, 16-byte trailer).  Thread-safe: the whole lookup / rebuild runs under the cache's lock, and a
+        pack built by a launch on ANOTHER stream is ordered before the caller's stream through the event recorded behind that
+        launch (two threads on one device with a stream each)."""
+        with self._lock:
+            out, order = self._get(weight, taps, transpose, bf16x3)
+            self._wait(order)
+            return out
+
+    @staticmethod
+    def _mark():
+        """(stream id, event recorded on it now): what a later consumer on a different stream has to wait for."""
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        st = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(st)
+        return [st.cuda_stream, ev]
+
+    @staticmethod
+    def _wait(order):
+        if order is None or order[1] is None:                        # (no launch to order against, or known complete)
+            return
+        if torch.cuda.is_current_stream_capturing():                  # (capture follows warm-up calls on the capture stream's side)
+            return
+        if order[1].query():
+            order[1] = None                                           # complete for every stream from now on: no more host calls
+            return
+        st = torch.cuda.current_stream()
+        if st.cuda_stream != order[0]:
+            st.wait_event(order[1])
+
+    def _get(self, weight, taps, transpose, bf16x3):
         import weakref
         bf16x3 = {False: 0, True: 1, "bf16x3": 1, "f16x3": 2, 0: 0, 1: 1, 2: 2}[bf16x3]      # = cmf_pack_desc.kind
         key = (id(weight), bool(transpose), bf16x3)
         ver = (weight._version, weight.data_ptr(), weight.device, tuple(weight.shape), self.generation)
         hit = self._store.get(key)
         if hit is not None and hit[0]() is weight and hit[1] == ver:
-            return hit[2]
+            return hit[2], hit[4]
         if (hit is not None and hit[0]() is weight and hit[1][:4] == ver[:4] and self.BATCHED_REFRESH
                 and self._refreshed.get(weight.device) != self.generation and not torch.cuda.is_current_stream_capturing()):
             # only the generation moved: an optimiser step rewrote the parameter VALUES (FlatOptimizer.step -> invalidate()).
             # Every pack of the model is stale in the same way: rebuild them all in ONE launch instead of one launch each --
             # once per generation and device (entries it had to skip are rebuilt singly below), never inside a graph capture
             # (the descriptor table is a host -> device copy)
-            with self._lock:
-                self._refresh_generation(weight.device)
-                self._refreshed[weight.device] = self.generation
+            self._refresh_generation(weight.device)
+            self._refreshed[weight.device] = self.generation
             hit = self._store.get(key)
             if hit[1] == ver:
-                return hit[2]
+                return hit[2], hit[4]
         lib = _lib.load()
         cout, cin = int(weight.shape[0]), int(weight.shape[1])
         n = C.c_longlong(0)
@@ -287,8 +317,9 @@ class _PackCache:
             _lib.check(lib.cmf_pack_weight(_p(w), _p(out), cout, cin, taps, int(transpose), None, _stream()), "cmf_pack_weight")
         if len(self._store) > 4096:                                   # drop entries whose parameter is gone
             self._store = {k: v for k, v in self._store.items() if v[0]() is not None}
-        self._store[key] = (weakref.ref(weight), ver, out, int(taps))
-        return out
+        order = self._mark()
+        self._store[key] = (weakref.ref(weight), ver, out, int(taps), order)
+        return out, order
 
     #: False: every stale pack is rebuilt by its own launch on first use (rounds 1 - 2)
     BATCHED_REFRESH = True
@@ -297,7 +328,7 @@ class _PackCache:
         """Re-pack, in one ``cmf_pack_weights_batched`` launch, every entry on ``device`` whose parameter is alive and unchanged
         but for the generation counter (its values were rewritten under it by the fused optimiser step)."""
         todo = []
-        for key, (ref, ver, out, taps) in list(self._store.items()):     # snapshot: another thread may insert meanwhile
+        for key, (ref, ver, out, taps, _) in list(self._store.items()):
             w = ref()
             if (w is None or ver[4] == self.generation or w.device != device or not w.is_contiguous()
                     or (w._version, w.data_ptr(), w.device, tuple(w.shape)) != ver[:4]):
@@ -328,8 +359,9 @@ class _PackCache:
             table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
             self._tables[device] = (sig, table)
         _lib.check(_lib.load().cmf_pack_weights_batched(_p(table), len(todo), _stream()), "cmf_pack_weights_batched")
+        order = self._mark()                                          # one event behind the one launch, shared by its entries
         for key, w, ver, out, taps in todo:
-            self._store[key] = (self._store[key][0], ver[:4] + (self.generation,), out, taps)
+            self._store[key] = (self._store[key][0], ver[:4] + (self.generation,), out, taps, order)
 
 
 PACKS = _PackCache()

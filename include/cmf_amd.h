@@ -158,7 +158,8 @@ int cmf_conv_tangent_f16x3(const cmf_conv_tangent_args* a, void* stream);
 /* the same with the work-item size chosen by the caller: item_channels = 64 (a workgroup's item is a pixel tile x 16 samples x 64
  * output channels), 32 (half of a 64-channel group per item: twice the items, for launches that would leave most CUs without one)
  * or 0 = cmf_conv_tangent_f16x3's own choice (32 when the 64-channel items number at most half the CUs).  Results are
- * bit-identical between the two sizes.                                                                                       */
+ * bit-identical between the two sizes.  Launches on 4 x 8 pixel tiles (16- / 32-wide images) always run 32-channel items: the
+ * 64-channel form does not fit the 256 VGPRs of a wave there (it spilled to scratch).                                          */
 int cmf_conv_tangent_f16x3_item(const cmf_conv_tangent_args* a, int item_channels, void* stream);
 /* out[0] = max(out[0], max_i |x[i]|) over n floats (out is NOT cleared: the caller zeroes it or chains several tensors).   */
 int cmf_absmax(const float* x, long long n, float* out, void* stream);

@@ -367,7 +367,7 @@ def test_bench_contract_line():
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-                          "--batch", "32", "--cpu-batch", "1", "--leg-steps", "1"], capture_output=True, text=True, timeout=900)
+                          "--batch", "32", "--cpu-batch", "8", "--leg-steps", "1"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -386,6 +386,16 @@ def test_bench_contract_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and isinstance(c.get("cpu_model"), str) and c["cpu_model"]
+    # round 5 (SURVEY 8d's protocol): a warm-up call, then the cost at B/4, B/2, B; the median step beside the mean; the
+    # end-to-end roofline object from the dense algorithmic count W_alg
+    assert c["warmup_batch"] >= 1 and set(c["evals_per_s_by_batch"]) == {"2", "4", "8"} and c["value"] == c["evals_per_s_by_batch"]["8"]
+    assert d["ms_per_step_median"] > 0 and d["ms_per_step_minmax"][0] <= d["ms_per_step_median"] <= d["ms_per_step_minmax"][1]
+    assert abs(d["ms_per_step_median"] - d["ms_per_step"]) < 0.2 * d["ms_per_step"]
+    e = d["end_to_end"]
+    assert e["W_alg_gflop_per_eval"] == 290.42 and abs(e["W_alg_tflop_per_s"] - 290.42e-3 * d["value"]) < 1e-6 * e["W_alg_tflop_per_s"]
+    assert abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-12 and 0 < e["frac"] < 1 and e["peak"] == 2500.0
+    assert e["skipped_of_dense_hidden_convs"] == {"launch_equivalents": 19.5, "of": 160, "zero_input_couplers": 1}
+    assert "r04_mfma_sustained" in d["roofline"]["live_data_mfma_ceiling"]["source"]
     # round 4 (SURVEY 8d "per-stage times"): stages in ms / step that sum to ms_per_step (host_gap is the remainder)
     st = d["stages"]
     names = ("encode", "primal", "tangent_hidden", "tangent_first_last", "acl", "gram_cholesky", "other", "host_gap")

@@ -27,7 +27,8 @@ def demangle(names):
     if not os.path.exists(filt):
         return list(names)
     out = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
-    return [re.sub(r"^void \(anonymous namespace\)::|^\(anonymous namespace\)::", "", re.sub(r"\(.*$", "", o)) for o in out]
+    clean = lambda o: re.sub(r"\(.*$", "", o.replace("(anonymous namespace)::", "").replace("void ", "", 1)).strip()
+    return [clean(o) for o in out]
 
 
 def resources(path, extra_flags=()):
