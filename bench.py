@@ -89,6 +89,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-legs", action="store_true", help="default C3 run only: skip the secondary measurements (N = 1: c5, c2b, "
                                                             "c5_train, train; N > 1: strong_c3, c5)")
     ap.add_argument("--leg-steps", type=int, default=10, help="timed steps of each secondary measurement")
+    ap.add_argument("--train-batch", type=int, default=64, help="samples per GPU of the C3 training leg (64 = the reference's per-GPU "
+                                                                 "shard, BASELINE configs[3]; smaller only to rehearse many ranks on one GPU)")
     ap.add_argument("--force-group", action="store_true",
                     help="N = 1: build a ONE-rank process group anyway and route the timing through its collectives (barrier, "
                          "(sum, count) all-reduce, MAX of the times) -- RCCL itself on a one-GPU box (tests/test_gpu_round4.py)")
@@ -699,6 +701,7 @@ def run_rank(args):
     if not args.no_kernel_timer and graph is None:
         select = (lambda name: name == HIDDEN_CONV) if args.config in ("c3", "c5") else (lambda name: True)
     dt, loss, rows, seen = eval_timed(wl, world, args.steps, args.warmup, select, graph, grouped)
+    step_ms = sorted(wl.step_ms)                             # the headline's own steps (later legs re-use ``wl``)
     if graph is not None and not args.no_kernel_timer:       # replayed graphs cannot carry events: eager steps, outside the timed region
         _, _, rows, _ = eval_timed(wl, world, 3, 1, lambda name: True, None)
 
@@ -719,8 +722,8 @@ def run_rank(args):
         # samples per GPU = configs[3]'s shard) with the faster one.  Last on this model: the optimiser steps change its weights
         n_par = sum((p.numel() + 3) // 4 * 4 for p in inner.parameters() if p.requires_grad)
         legs["grad_reduce"] = grad_reduce_leg(n_par, rank, world, device)
-        x64 = synth_batch(dataset, shape, 64, rank, device)
-        legs["train"] = train_leg(args.leg_steps, 1, "c3", inner, x64, 64, rank, world, device, off, legs["grad_reduce"]["used"])
+        x64 = synth_batch(dataset, shape, args.train_batch, rank, device)
+        legs["train"] = train_leg(args.leg_steps, 1, "c3", inner, x64, args.train_batch, rank, world, device, off, legs["grad_reduce"]["used"])
     f32 = None
     if default_run and world == 1:
         def f32_exact():
@@ -750,8 +753,8 @@ def run_rank(args):
 
         def train():
             # last on this model: the optimiser steps change its weights (C3 model, the reference's 64-sample C4 shard)
-            x64 = synth_batch(dataset, shape, 64, rank, device)
-            return train_leg(args.leg_steps, 1, "c3", inner, x64, 64, rank, world, device, off)
+            x64 = synth_batch(dataset, shape, args.train_batch, rank, device)
+            return train_leg(args.leg_steps, 1, "c3", inner, x64, args.train_batch, rank, world, device, off)
 
         if not args.no_f32_exact:
             f32 = guarded("f32_exact", f32_exact, world)
@@ -782,10 +785,9 @@ def run_rank(args):
             line["roofline"] = roofline_of(name, n, ms, fl, by, step_ms, args.precision, B, pmc=(args.config == "c3"))
             if args.graph:
                 line["roofline"]["note"] = "kernel events from 3 eager steps after the timed graph replays; share_of_step = share of GPU kernel time"
-        med = sorted(wl.step_ms)[len(wl.step_ms) // 2] if len(wl.step_ms) % 2 else \
-            0.5 * (sorted(wl.step_ms)[len(wl.step_ms) // 2 - 1] + sorted(wl.step_ms)[len(wl.step_ms) // 2])
-        line["ms_per_step_median"] = med
-        line["ms_per_step_minmax"] = [min(wl.step_ms), max(wl.step_ms)]
+        n_ = len(step_ms)
+        line["ms_per_step_median"] = step_ms[n_ // 2] if n_ % 2 else 0.5 * (step_ms[n_ // 2 - 1] + step_ms[n_ // 2])
+        line["ms_per_step_minmax"] = [step_ms[0], step_ms[-1]]
         line["end_to_end"] = end_to_end(args.config, B * world * args.steps / dt, args.precision, inner)
         if stages is not None:
             line["stages"] = stages
@@ -801,6 +803,7 @@ def run_rank(args):
         if world == 1 and args.cpu_batch > 0:
             line["cpu_baseline"] = guarded("cpu_baseline", lambda: cpu_baseline(schema, shape, {k: v.cpu() for k, v in sd.items()},
                                                                                 args.cpu_batch, dataset, off, label), 1)
+        line["printed_at_unix"] = time.time()               # (a launcher test bounds the teardown: process-group destruction, exit)
         print(json.dumps(line), flush=True)
     if grouped:
         dist.destroy_process_group()

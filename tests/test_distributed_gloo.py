@@ -186,7 +186,7 @@ def _sum_flat_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])             # 8 = the node the driver scales to
 def test_reduce_scatter_all_gather_sums_like_all_reduce(world):
     """``sum_flat``'s two shapes (one all-reduce; reduce-scatter + all-gather over equal, zero-padded slices) give every rank the
     same sums -- the float64 sum of the ranks' buckets to fp32 rounding, and bit-identical to each other at two ranks (one

@@ -280,3 +280,30 @@ def test_checkerboard_tail_of_the_coupler_networks_is_bit_identical(name, B, mon
         assert torch.equal(out[True][k], out[False][k]), (name, B, k, rel(out[True][k], out[False][k]))
     assert out[True]["launches"].get("conv_tangent_t9_ci64_co64_live") == 7 and "conv_tangent_t9_ci64_co64_live" not in out[False]["launches"]
     assert out[False]["launches"]["conv_tangent_t9_ci64_co64"] - out[True]["launches"]["conv_tangent_t9_ci64_co64"] == 7
+
+
+def test_bench_launches_four_ranks_from_a_bare_shell_and_tears_down():
+    """Rehearsal of the driver's multi-GPU launch on a one-GPU box: ``python bench.py --gpus 4`` from a bare environment (fresh
+    children, never a re-exec; gloo + one shared GPU), every N > 1 leg of the line present and seen by 4 ranks, and the job gone
+    within 30 s of rank 0 printing its line (process-group destruction and exit of every rank).  FOUR ranks, not eight: this pool
+    allows at most 6 processes on a card at once and the test process itself holds the GPU (4 + 1 <= 6); the 8-rank launch path
+    is the same code with a larger range()."""
+    import json, os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--backend", "gloo", "--share-gpu", "--batch", "8",
+                        "--steps", "1", "--warmup", "1", "--leg-steps", "1", "--train-batch", "8", "--cpu-batch", "0"],
+                       capture_output=True, text=True, env=env, timeout=1500, cwd=root)
+    t_exit = time.time()
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["ranks_seen"] == 4 and d["config"]["global_batch"] == 32 and "REHEARSAL" in d["data"]
+    for leg in ("strong_c3", "c5", "grad_reduce", "train"):
+        assert leg in d and "error" not in d[leg], leg
+    assert d["strong_c3"]["ranks_seen"] == 4 and d["strong_c3"]["per_gpu_batch"] == 128 and d["strong_c3"]["global_batch"] == 512
+    assert d["c5"]["ranks_seen"] == 4 and d["c5"]["global_batch"] == 128
+    assert d["train"]["n_gpus"] == 4 and d["train"]["config"]["global_batch"] == 32 and d["train"]["config"]["gradient_reduction"] == d["grad_reduce"]["used"]
+    assert 0 <= t_exit - d["printed_at_unix"] < 30, (t_exit - d["printed_at_unix"], t_exit - t0)
