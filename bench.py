@@ -470,7 +470,7 @@ def roofline_of(name, n, ms, flops, nbytes, step_ms_total, precision, B, pmc=Tru
                 # context, not the contract's peak: what a loop of nothing but this MFMA sustains on live random operands on every
                 # SIMD (tools/ubench/mfmapower.py, profiles/r03_mfma_sustained.txt: the chip lowers its clock under the load)
                 "live_data_mfma_ceiling": {"frac_of_peak": 0.72, "frac_of_ceiling": 3.0 * tf / BF16_MFMA_PEAK_TFLOPS / 0.72,
-                                           "source": "profiles/r04_mfma_sustained.txt (tools/ubench/mfmapower.py, 16x16x32 bf16, changing random "
+                                           "source": "profiles/r05_mfma_sustained.txt (tools/ubench/mfmapower.py, 16x16x32 bf16, changing random "
                                                      "operands, 2 waves / SIMD; measured once per round, not by this run)"},
                 "hbm_view": {"algorithmic_gbs": gbs, "peak_gbs": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}, **common}
     if name.startswith("conv_tangent") or name.startswith("mlp_") or name == "gram_cholesky":
@@ -701,7 +701,7 @@ def run_rank(args):
     if not args.no_kernel_timer and graph is None:
         select = (lambda name: name == HIDDEN_CONV) if args.config in ("c3", "c5") else (lambda name: True)
     dt, loss, rows, seen = eval_timed(wl, world, args.steps, args.warmup, select, graph, grouped)
-    step_ms = sorted(wl.step_ms)                             # the headline's own steps (later legs re-use ``wl``)
+    per_step = sorted(wl.step_ms)                            # the headline's own steps (later legs re-use ``wl``)
     if graph is not None and not args.no_kernel_timer:       # replayed graphs cannot carry events: eager steps, outside the timed region
         _, _, rows, _ = eval_timed(wl, world, 3, 1, lambda name: True, None)
 
@@ -785,9 +785,9 @@ def run_rank(args):
             line["roofline"] = roofline_of(name, n, ms, fl, by, step_ms, args.precision, B, pmc=(args.config == "c3"))
             if args.graph:
                 line["roofline"]["note"] = "kernel events from 3 eager steps after the timed graph replays; share_of_step = share of GPU kernel time"
-        n_ = len(step_ms)
-        line["ms_per_step_median"] = step_ms[n_ // 2] if n_ % 2 else 0.5 * (step_ms[n_ // 2 - 1] + step_ms[n_ // 2])
-        line["ms_per_step_minmax"] = [step_ms[0], step_ms[-1]]
+        n_ = len(per_step)
+        line["ms_per_step_median"] = per_step[n_ // 2] if n_ % 2 else 0.5 * (per_step[n_ // 2 - 1] + per_step[n_ // 2])
+        line["ms_per_step_minmax"] = [per_step[0], per_step[-1]]
         line["end_to_end"] = end_to_end(args.config, B * world * args.steps / dt, args.precision, inner)
         if stages is not None:
             line["stages"] = stages

@@ -97,6 +97,7 @@ SIGNATURES = {
     "cmf_gram_backward": (_i, [_fp, _ll, _ll, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _ll, _ll, _fp]),
     "cmf_prehead": (_i, [_fp, _fp, _fp, _fp, _f, _f, _i, _i, _i, _fp]),
     "cmf_prehead_inverse": (_i, [_fp, _fp, _f, _f, _i, _ll, _fp]),
+    "cmf_expand_columns": (_i, [_fp, _i, _fp, _i, _fp, _ll, _fp]),
     "cmf_gaussian_logprob": (_i, [_fp, _ll, _i, _i, _fp, _fp]),
     "cmf_affine_prior": (_i, [_fp, _ll, _fp, _fp, _i, _i, _i, _fp, _fp]),
     "cmf_recon_sqerr": (_i, [_fp, _fp, _i, _i, _fp, _fp]),

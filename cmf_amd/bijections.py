@@ -145,7 +145,7 @@ class AffineCouplingBijection(Bijection):
         """Flat element ids of z the coupler network reads (its "pass-through" input)."""
         raise NotImplementedError
 
-    def decode_(self, z, T=None, lj=None, ncols=None, zero_in=False):
+    def decode_(self, z, T=None, lj=None, ncols=None, zero_in=False, seed_columns=None):
         view = self.view(z.device)
         if zero_in and self.net.kind == "resnet":
             y, g = E.net_primal_zero_input(self.net, view, z.shape[0], z.device)
@@ -158,7 +158,16 @@ class AffineCouplingBijection(Bijection):
         # the split-precision tangent pass reads relu' from bit masks written by the primal pass (engine.BitMask)
         want = False if T is None else ("bits" if E.cfg().tangent == "bf16x3" else True)
         y, g, acts = E.net_primal(self.net, z, view, need_acts=want)
-        if T is not None:
+        if T is not None and seed_columns is not None:
+            # first layer of the decode sweep (FlowProgram._seed_columns): T holds the tail's one-hot seeds, and only the columns
+            # seeded at a pass-through element have a non-zero network tangent -- the network runs on those, packed
+            sc = seed_columns
+            Tc = E.seed_tangent(T.B, T.N, sc["nc"], T.layout, sc["col_of"], sc["n"], z.device)
+            YTc = E.net_tangent(self.net, Tc, view, acts)
+            YT = E.expand_columns(YTc, T.nc, sc["colmap"])
+            YT.compact = getattr(YTc, "compact", False)
+            self._acl_tangent(T, YT, z, y, g)
+        elif T is not None:
             YT = E.net_tangent(self.net, T, view, acts)
             self._acl_tangent(T, YT, z, y, g)                       # uses z BEFORE the primal update
         E.acl_primal(z, y, self.maps(z.device), decode=True, lj=lj)

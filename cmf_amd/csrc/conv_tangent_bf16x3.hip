@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void conv_tangent_bf16x3_kernel(cmf_conv_ta
   }
 #ifdef CMF_DBG_REPEAT
   // timing only: every workgroup walks its item list CMF_DBG_REPEAT times in ONE launch (same arguments, same outputs) -- what R
-  // launches cost without R - 1 of their fills and drains: the ceiling of one persistent launch per coupler network
+  // launches cost without R - 1 of their fills and drains: the ceiling of one persistent launch per coupler network (profiles/LABBOOK.md, round 4: section 9 item 0a)
   const int n_real = jx < xlen ? (xlen - jx + nbx - 1) / nbx : 0;
   const int n_items = n_real * CMF_DBG_REPEAT;
 #else

@@ -15,7 +15,7 @@
 //     all four output-channel tiles x input-channel tile w x nine taps = 36 accumulator tiles (144 VGPRs): 26 ds_read_b128 and
 //     108 MFMAs of 16 cycles per slot, against 72 fp32 MFMAs of 32 cycles for half the K in conv_wgrad.hip;
 //   * rows are dealt XCD-aware so that the three uses of an input row are L2 hits (below).
-// History of the structure, each step from a measurement: every wave playing both roles with two fragments and 18
+// History of the structure, each step from a measurement (profiles/LABBOOK.md section 4.6): every wave playing both roles with two fragments and 18
 // tiles each ran 210 -> 296 TFLOP/s fp32-equivalent with deeper prefetch, fewer fragment reads and the row dealing, and stopped
 // there -- its fetch + split half alone took 1.0 ms, its MFMA half 1.2 ms, together 1.6 ms (B = 128, 28 x 28): a SIMD does not
 // overlap one wave's VALU / SALU stream with another wave's MFMAs for free.  Stamps on the role-specialised form then showed the

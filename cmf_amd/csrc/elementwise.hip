@@ -252,6 +252,23 @@ __global__ void seed_tangent_kernel(float* __restrict__ t, long long t_b, long l
   reinterpret_cast<f32x4*>(t + b * t_b + (long long)r * t_r)[c4] = v;
 }
 
+// column expansion of a tangent tensor: out(row, c) = colmap[c] >= 0 ? in(row, colmap[c]) : 0; flat over (row, c4)
+__global__ void expand_columns_kernel(const float* __restrict__ in, int nc_in, float* __restrict__ out, int nc4,
+                                      const int* __restrict__ colmap, long long total) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const int c4 = (int)(i % nc4);
+  const long long row = i / nc4;
+  const float* src = in + row * nc_in;
+  f32x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = colmap[c4 * 4 + k];
+    v[k] = j >= 0 ? src[j] : 0.f;
+  }
+  reinterpret_cast<f32x4*>(out + row * (long long)nc4 * 4)[c4] = v;
+}
+
 // (B, N) <-> (B/16, N, 16): 16 x 16 transposes through registers of one 16-lane group
 __global__ void primal_regroup_kernel(const float* __restrict__ in, float* __restrict__ out, int B, long long N,
                                       int to_grouped) {
@@ -486,6 +503,15 @@ int cmf_seed_tangent(float* t, long long t_b, long long t_r, const int* col_of, 
   const long long total = (long long)B * n_rows * (nc / 4);
   hipLaunchKernelGGL(seed_tangent_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, t, t_b, t_r, col_of,
                      n_rows, nc / 4, eps, d, S, total);
+  CMF_LAUNCH_CHECK();
+  return 0;
+}
+
+int cmf_expand_columns(const float* in, int nc_in, float* out, int nc_out, const int* colmap, long long rows, void* stream) {
+  if (!in || !out || !colmap || nc_in <= 0 || nc_out <= 0 || nc_out % 4 || rows <= 0 || (uintptr_t)out % 16) return CMF_EINVAL;
+  const long long total = rows * (nc_out / 4);
+  hipLaunchKernelGGL(expand_columns_kernel, dim3(nblocks(total)), dim3(TPB), 0, (hipStream_t)stream, in, nc_in, out, nc_out / 4,
+                     colmap, total);
   CMF_LAUNCH_CHECK();
   return 0;
 }

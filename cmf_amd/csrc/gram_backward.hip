@@ -10,7 +10,7 @@
 // G is the matrix the forward kernel left in `jtj` (jitter included: a constant shift of the diagonal has no
 // derivative of its own).  G^-1 comes from an in-place Gauss-Jordan sweep in LDS (no pivoting: G is SPD,
 // the forward pass has already factorised it), the product runs on the vector ALUs: 2 D d^2 FLOP per sample
-// is < 1 % of the reverse sweep it feeds, so this kernel is written for clarity, not MFMA.
+// is < 1 % of the reverse sweep it feeds (profiles/LABBOOK.md section 9, f1), so this kernel is written for clarity, not MFMA.
 #include "common.h"
 
 namespace {

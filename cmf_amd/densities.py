@@ -353,6 +353,45 @@ class FlowProgram:
     def _zero(self, i):
         return self.SKIP_STRUCTURAL_ZEROS and self.zero_in.get(i, False)
 
+    #: False: the first decoded coupler's network sees all d Jacobian columns (rounds 1 - 4)
+    SEED_COLUMNS = True
+
+    def _seed_columns(self, dev):
+        """The FIRST coupling layer of the decode sweep sees the one-hot seed tangents of the tail (non_square.py:303-304, :406-410):
+        Jacobian column k is a unit vector at element ``permutation[k]``.  Its network reads only its pass-through elements, and its
+        tangent map is linear, so column k's network tangent is identically zero there unless that element is a pass-through one:
+        the network runs on THOSE columns only (packed into fewer 16-column slices) and its output is expanded back
+        (``cmf_expand_columns``) -- the other columns' rows are scaled by e^{-s}, exactly what the full computation gives them.
+        About half the columns on average (a checkerboard layer passes half the elements): C3's recipe model 36 of 64 -> 48 slots,
+        C5's 71 of 128 -> 80.  Returns {"index": layer index, "col_of", "colmap": device int32 maps, "nc": packed column slots} or
+        None.  The plan depends on the tail's permutation BUFFER (a model constant, saved in checkpoints): read once on the host and
+        cached until that buffer changes; nothing here depends on the batch."""
+        if not (self.SEED_COLUMNS and self.image and self.layers):
+            return None
+        first = self.layers[-1]
+        if not (isinstance(first, AffineCouplingBijection) and first.net.kind == "resnet") or self.zero_in.get(len(self.layers) - 1):
+            return None
+        perm = self.tail.permutation
+        key = (perm._version, perm.data_ptr(), str(dev))
+        hit = getattr(self, "_seed_cols", None)
+        if hit is None or hit[0] != key:
+            pos = perm[: self.d].detach().cpu().numpy()                 # element of latent k (one device-to-host copy per model)
+            is_pass = np.zeros(first.geom.N, dtype=bool)
+            is_pass[first.pass_elements()] = True
+            cols = [k for k in range(self.d) if is_pass[pos[k]]]
+            nc, ncc = E.ceil16(self.d), E.ceil16(max(len(cols), 1))
+            plan = None
+            if ncc < nc:
+                col_of = np.full(first.geom.N, -1, dtype=np.int32)
+                colmap = np.full(nc, -1, dtype=np.int32)
+                for j, k in enumerate(cols):
+                    col_of[pos[k]] = j
+                    colmap[k] = j
+                plan = {"index": len(self.layers) - 1, "nc": ncc, "n": len(cols), "col_of": torch.from_numpy(col_of).to(dev),
+                        "colmap": torch.from_numpy(colmap).to(dev)}
+            self._seed_cols = hit = (key, plan)
+        return hit[1]
+
     # -- per-sample tangent footprint, for sub-batching ------------------------------------------
     def tangent_bytes_per_sample(self, nc):
         worst = 0
@@ -473,12 +512,14 @@ class FlowProgram:
         scatter = self.tail.scatter_index(dev)
         z = E.gather_primal(z_low.contiguous(), scatter, N).view(B, *self.tail.x_shape)
         T, ncols = None, None
+        seed = None
         if tangents:
             ncols = self.d if eps is None else eps.shape[2]
             T = E.seed_tangent(B, N, E.ceil16(ncols), self.layout, scatter, self.d, dev, eps=eps)
+            seed = self._seed_columns(dev) if eps is None else None      # (probe directions are dense: every column is live)
         for i, m in self._decode_order():
             if isinstance(m, AffineCouplingBijection):
-                m.decode_(z, T, ncols=ncols, zero_in=self._zero(i))
+                m.decode_(z, T, ncols=ncols, zero_in=self._zero(i), seed_columns=seed if seed is not None and seed["index"] == i else None)
             elif isinstance(m, SplitDensity):
                 n = z[0].numel()                 # zero-pad the dropped half (split.py:50-52)
                 idx = torch.cat((torch.arange(n, dtype=torch.int32, device=dev),

@@ -562,6 +562,15 @@ def gather_tangent(T, idx, n_out):
     return out
 
 
+def expand_columns(T, nc_out, colmap):
+    """A panel-layout tangent stack with ``nc_out`` column slots: column c = column ``colmap[c]`` of ``T`` (or zero where -1)."""
+    assert T.layout == "panel"
+    out = Tangent(T.B, T.N, nc_out, "panel", T.data.device)
+    _lib.check(_lib.load().cmf_expand_columns(_p(T.data), T.nc, _p(out.data), int(nc_out), _p(colmap), T.B * T.N, _stream()),
+               "cmf_expand_columns")
+    return out
+
+
 def seed_tangent(B, N, nc, layout, col_of, d, device, eps=None):
     T = Tangent(B, N, nc, layout, device)
     S = 0 if eps is None else int(eps.shape[2])

@@ -271,6 +271,11 @@ int cmf_gather_primal(const float* in, long long in_b, float* out, long long out
                       int n_out, int B, void* stream);
 int cmf_gather_tangent(const float* in, long long in_b, long long in_r, float* out, long long out_b,
                        long long out_r, const int* idx, int n_out, int nc, int B, void* stream);
+/* Column expansion of a contiguous tangent tensor of `rows` rows: out(row, c) = colmap[c] >= 0 ? in(row, colmap[c]) : 0 for c <
+ * nc_out (nc_out % 4 == 0).  The first coupling layer of the decode sweep sees one-hot seed tangents (non_square.py:303-304): a
+ * Jacobian column whose seed element is not among the elements that layer's network reads has an identically zero network tangent
+ * there, so the network runs on the other columns only (nc_in of them, packed) and its output is expanded back with this.    */
+int cmf_expand_columns(const float* in, int nc_in, float* out, int nc_out, const int* colmap, long long rows, void* stream);
 /* Seed tangents at the tail (non_square.py:303-304, :406-410): col_of[r] = Jacobian column whose unit
  * vector lands on element r (or -1).  eps == NULL: T(b, r, c) = (col_of[r] == c)  (identity seed, exact
  * path); else T(b, r, c) = eps[b][col_of[r]][c] for c < S (Hutchinson probes, non_square.py:204-215).  */

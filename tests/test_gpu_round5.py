@@ -307,3 +307,42 @@ def test_bench_launches_four_ranks_from_a_bare_shell_and_tears_down():
     assert d["c5"]["ranks_seen"] == 4 and d["c5"]["global_batch"] == 128
     assert d["train"]["n_gpus"] == 4 and d["train"]["config"]["global_batch"] == 32 and d["train"]["config"]["gradient_reduction"] == d["grad_reduce"]["used"]
     assert 0 <= t_exit - d["printed_at_unix"] < 30, (t_exit - d["printed_at_unix"], t_exit - t0)
+
+
+@pytest.mark.parametrize("name,B", [("c3_mnist_full", 2), ("c3_mnist_full", 32), ("c5_cifar_full", 16), ("c3_mnist_full_cond", 2)])
+def test_first_coupler_on_its_live_seed_columns_is_bit_identical(name, B):
+    """The first decoded coupler's tangent network on the Jacobian columns seeded at its pass-through elements only (packed,
+    expanded back by cmf_expand_columns) against all d columns: x_hat, J, J^T J, log-det, g_ij, elbo ``torch.equal``; and the
+    column expansion itself against torch indexing."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    prog = head.program
+    x = _batch(g, B)
+    plan = prog._seed_columns(x.device)
+    assert plan is not None and plan["nc"] < E.ceil16(prog.d) and plan["n"] <= plan["nc"]
+    out = {}
+    with torch.no_grad():
+        z_low = prog.encode(x)[0]
+        for mode in (True, False):
+            prog.SEED_COLUMNS = mode
+            try:
+                x_hat, T = prog.decode(z_low, tangents=True)
+                gr = E.gram_cholesky(T, prog.d)
+                elbo = head.elbo(x.clone(), add_offdiagonal_metric_reg=True)["elbo"]
+            finally:
+                del prog.SEED_COLUMNS
+            out[mode] = dict(x_hat=x_hat.clone(), J=T.to_dense(prog.d).clone(), jtj=gr.jtj.clone(), logdet=gr.logdet.clone(), l1=gr.l1_off.clone(),
+                             elbo=elbo.clone())
+    for k in ("x_hat", "J", "jtj", "logdet", "l1", "elbo"):
+        assert torch.equal(out[True][k], out[False][k]), (name, B, k, rel(out[True][k], out[False][k]))
+    # the expansion kernel
+    gen = torch.Generator().manual_seed(1)
+    src = E.Tangent(3, 50, 32, "panel", "cuda", data=torch.randn(3 * 50 * 32, generator=gen).cuda())
+    cmap = torch.full((64,), -1, dtype=torch.int32)
+    sel = torch.randperm(64, generator=gen)[:20]
+    cmap[sel] = torch.randperm(32, generator=gen)[:20].to(torch.int32)
+    got = E.expand_columns(src, 64, cmap.cuda()).data.view(150, 64).cpu()
+    want = torch.zeros(150, 64)
+    want[:, sel] = src.data.view(150, 32).cpu()[:, cmap[sel].long()]
+    assert torch.equal(got, want)

@@ -301,3 +301,34 @@ def test_structural_zero_plan_matches_the_oracles_data(name):
         assert isinstance(prog.layers[i + 1], SplitDensity)   # decode order runs the list backwards
     else:
         assert not prog.zero_in
+
+
+@pytest.mark.parametrize("name", ["mini_mnist", "mini_cifar", "c3_mnist_full"])
+def test_seed_column_plan_matches_the_oracles_data(name):
+    """``FlowProgram._seed_columns``: the Jacobian columns whose tangent the FIRST decoded coupler's network sees as non-zero are
+    exactly the ones the plan packs -- checked on the oracle's own tangents (tail scatter of the identity, times the layer's mask)."""
+    from cmf_amd.bijections import AffineCouplingBijection
+    g, meta = load_golden(name)
+    dens = cmf_amd.get_density(cmf_amd.get_schema(cmf_amd.get_config(meta["dataset"], **meta["overrides"])), g["x"])
+    prog = _find(dens, "NonSquareHeadDensity").program
+    _, _, _, ops, sd = golden_model(meta)
+    dens.load_state_dict({k: v for k, v in sd.items()}, strict=False)          # the fixture's permutation buffers
+    _, _, flow_ops, base, _ = O.split_ops(ops)
+    d = base["d"]
+    hv = O.tail_scatter(sd, base, torch.eye(d).expand(1, d, d))                 # (1, d, *x_shape): column k's seed tangent
+    op = [o for o in flow_ops if o["kind"] == "acl"][-1]                        # first in decode order
+    assert op["mask_type"] == "checkerboard"
+    seen = (sd[op["prefix"] + "mask"] * hv).flatten(2).abs().amax(2)[0] > 0     # columns with a non-zero network input
+    plan = prog._seed_columns("cpu")
+    first = prog.layers[-1]
+    assert isinstance(first, AffineCouplingBijection)
+    cols = [k for k in range(d) if bool(seen[k])]
+    if plan is None:
+        assert (len(cols) + 15) // 16 * 16 >= (d + 15) // 16 * 16 or first.net.kind != "resnet"
+        return
+    colmap = plan["colmap"].numpy()
+    assert [k for k in range(d) if colmap[k] >= 0] == cols and plan["n"] == len(cols) and plan["nc"] == (len(cols) + 15) // 16 * 16
+    assert sorted(colmap[colmap >= 0].tolist()) == list(range(len(cols)))
+    col_of = plan["col_of"].numpy()
+    pos = prog.tail.permutation[:d].numpy()
+    assert all(col_of[pos[k]] == colmap[k] for k in cols) and int((col_of >= 0).sum()) == len(cols)

@@ -192,7 +192,7 @@ def test_one_ulp_input_sensitivity_of_the_oracle():
     d_ld = ((a["logdet"] - b["logdet"]).abs() / a["logdet"].abs()).flatten()
     d_l1 = ((a["l1"] - b["l1"]).abs() / a["l1"].abs()).flatten()
     # smooth sensitivity is ~1e-6; the assertion only pins that the yardstick is finite and small for the mini model --
-    # the full-size numbers (4.3 M activations per sample) are produced by tests/dev/one_ulp_full.py and recorded in DESIGN 4.2
+    # the full-size numbers (4.3 M activations per sample) are produced by tests/dev/one_ulp_full.py and recorded in profiles/LABBOOK.md section 4.2
     assert float(d_ld.max()) < 1e-3 and float(d_l1.max()) < 1e-3
     assert float(d_ld.median()) < 1e-4
 

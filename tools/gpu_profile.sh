@@ -19,7 +19,9 @@ python3 tools/rocprof_stats.py $out/stats $out/kernel_stats.csv > /dev/null 2>&1
 NOTE="rocprofv3 --pmc <group> --kernel-trace -- $B1 (separate passes: SQ group / FETCH_SIZE / WRITE_SIZE)"
 python3 tools/pmc_kernel.py --out $out/pmc_gram_cholesky.json --kernel gram_chol --note "$NOTE" $out/pmc_sq $out/pmc_fetch $out/pmc_write > /dev/null 2>&1
 python3 tools/pmc_kernel.py --out $out/pmc_acl_tangent.json --kernel acl_tangent --note "$NOTE" $out/pmc_sq $out/pmc_fetch $out/pmc_write > /dev/null 2>&1
-python3 tools/pmc_kernel.py --source cmf_amd/csrc/conv_tangent_bf16x3.hip --out $out/pmc_conv_tangent_bf16x3.json --kernel "conv_tangent_bf16x3_kernel<4, 7, 3," --note "$NOTE" $out/pmc_sq $out/pmc_fetch $out/pmc_write > /dev/null 2>&1
+python3 tools/pmc_kernel.py --source cmf_amd/csrc/conv_tangent_bf16x3.hip --out $out/pmc_conv_tangent_bf16x3.json --kernel "conv_tangent_bf16x3_kernel<4, 7, 3, false, false, false>" --note "$NOTE" $out/pmc_sq $out/pmc_fetch $out/pmc_write > /dev/null 2>&1
+# round 5: the checkerboard-output form (the last hidden conv of the seven checkerboard couplers: 7 launches per step)
+python3 tools/pmc_kernel.py --source cmf_amd/csrc/conv_tangent_bf16x3.hip --out $out/pmc_conv_tangent_bf16x3_live.json --kernel "conv_tangent_bf16x3_kernel<4, 7, 3, false, false, true>" --note "$NOTE" $out/pmc_sq $out/pmc_fetch $out/pmc_write > /dev/null 2>&1
 python3 tools/pmc_kernel.py --source cmf_amd/csrc/conv_tangent_bf16x3.hip --out $out/pmc_conv_tangent_f16x3.json --kernel "conv_tangent_bf16x3_kernel<4, 7, 2, true" --note "$NOTE" $out/pmc_sq $out/pmc_fetch $out/pmc_write > /dev/null 2>&1
 python3 tools/pmc_kernel.py --source cmf_amd/csrc/conv_tangent.hip --out $out/pmc_conv_tangent_thin.json --kernel "conv_tangent_thin_kernel" --note "$NOTE" $out/pmc_sq $out/pmc_fetch $out/pmc_write > /dev/null 2>&1
 rm -rf $out/stats $out/pmc_sq $out/pmc_fetch $out/pmc_write

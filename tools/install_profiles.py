@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(src, "bench_*.json")):
 cp(os.path.join(src, "bench_c3.json"), f"{pre}_bench_default.json")
 cp(os.path.join(src, "eval", "kernel_stats.csv"), f"{pre}_kernel_stats_bf16x3.csv")
 cp(os.path.join(src, "eval", "kernel_table.txt"), f"{pre}_kernel_table.txt")
-for k in ("conv_tangent_bf16x3", "gram_cholesky", "acl_tangent", "conv_tangent_f16x3", "conv_tangent_thin"):
+for k in ("conv_tangent_bf16x3", "conv_tangent_bf16x3_live", "gram_cholesky", "acl_tangent", "conv_tangent_f16x3", "conv_tangent_thin"):
     cp(os.path.join(src, "eval", f"pmc_{k}.json"), f"{pre}_pmc_{k}.json")
 cp(os.path.join(src, "eval", "pmc_conv_tangent_bf16x3.json"), "pmc_conv_tangent_bf16x3.json")   # bench.py's roofline.traffic reads this one
 cp(os.path.join(src, "train", "kernel_stats.csv"), f"{pre}_train_kernel_stats.csv")

@@ -15,7 +15,8 @@ fi
 # the PMC passes first: bench.py's roofline.traffic cites profiles/pmc_conv_tangent_bf16x3.json, stamped with the kernel source's hash
 bash tools/gpu_profile.sh $tag/eval > $out/eval_profile.log 2>&1 || { tail -5 $out/eval_profile.log; exit 1; }
 cp $out/eval/pmc_conv_tangent_bf16x3.json profiles/pmc_conv_tangent_bf16x3.json
-timeout -k 10 400 python bench.py > $out/bench_c3.json 2> $out/bench_c3.err || exit 1       # the default line: headline + every leg
+timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $out/bench_c3.json 2> $out/bench_c3.err || exit 1   # the default line as the driver runs it: headline + every leg
+timeout -k 10 200 python bench.py --config c5 --batch 256 --steps 5 --cpu-batch 0 > $out/bench_c5_b256.json 2>/dev/null || exit 1   # configs[4] on ONE GPU
 for c in c1 c2a c2b c5; do timeout -k 10 200 python bench.py --config $c > $out/bench_$c.json 2>/dev/null || exit 1; done
 timeout -k 10 200 python bench.py --config c5 --hutchinson > $out/bench_c5_hutch.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --train --batch 64 > $out/bench_train.json 2>/dev/null || exit 1
