@@ -506,6 +506,14 @@ def end_to_end(config, evals_per_s, precision, density):
             skipped = sum(float(per[k]) if prog._zero(i) else (0.5 if getattr(m, "_live", None) else 0.0)
                           for k, (i, m) in enumerate((i, m) for i, m in enumerate(prog.layers) if m in acls))
             out["skipped_of_dense_hidden_convs"] = {"launch_equivalents": skipped, "of": sum(per), "zero_input_couplers": len(zero)}
+            dev = next(density.parameters()).device
+            seed = prog._seed_columns(dev)                   # the first decoded coupler runs on its live seed columns only
+            if seed is not None:
+                nc = (prog.d + 15) // 16 * 16
+                k = [i for i, m in enumerate(prog.layers) if m in acls].index(seed["index"])
+                full = per[k] - (0.5 if getattr(prog.layers[seed["index"]], "_live", None) else 0.0)
+                out["skipped_of_dense_hidden_convs"]["launch_equivalents"] += full * (1.0 - seed["nc"] / nc)
+                out["skipped_of_dense_hidden_convs"]["first_coupler_columns"] = {"live": seed["n"], "slots": seed["nc"], "of": nc}
     except Exception:                                       # noqa: BLE001 -- a note, never the measurement
         pass
     return out

@@ -394,7 +394,9 @@ def test_bench_contract_line():
     e = d["end_to_end"]
     assert e["W_alg_gflop_per_eval"] == 290.42 and abs(e["W_alg_tflop_per_s"] - 290.42e-3 * d["value"]) < 1e-6 * e["W_alg_tflop_per_s"]
     assert abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-12 and 0 < e["frac"] < 1 and e["peak"] == 2500.0
-    assert e["skipped_of_dense_hidden_convs"] == {"launch_equivalents": 19.5, "of": 160, "zero_input_couplers": 1}
+    # 16 (the zero-input coupler) + 7 x 0.5 (checkerboard tails) + 15.5 x (1 - 48 / 64) (the first coupler's 36 live seed columns)
+    assert e["skipped_of_dense_hidden_convs"] == {"launch_equivalents": 23.375, "of": 160, "zero_input_couplers": 1,
+                                                  "first_coupler_columns": {"live": 36, "slots": 48, "of": 64}}
     assert "r05_mfma_sustained" in d["roofline"]["live_data_mfma_ceiling"]["source"]
     # round 4 (SURVEY 8d "per-stage times"): stages in ms / step that sum to ms_per_step (host_gap is the remainder)
     st = d["stages"]
