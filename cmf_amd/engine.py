@@ -451,10 +451,11 @@ def conv_tangent(x_t, x_off, x_np, x_ci, x_px, weight, taps, y_t, y_np, y_co, y_
         return launch()
     # algorithmic work of this launch: 2*cin*cout*taps FLOP per output pixel and Jacobian column; every input,
     # output and residual element crosses HBM once (4 bytes each)
-    px = float(H) * W * nc * np_ * (0.5 if live else 1.0)
+    px_in = float(H) * W * nc * np_
+    px = px_in * (0.5 if live else 1.0)                     # checkerboard output: half the output pixels (and residual reads), every input pixel
     TIMER.wrap(f"conv_tangent_t{taps}_ci{cin}_co{cout}" + ("_primal" if fmode == F_SELF_RELU else "_primal_bwd" if pbwd else "_live" if live else ""),
                2.0 * cin * cout * taps * px,
-               4.0 * px * (cin + cout + (cout if res_t is not None else 0)), launch)
+               4.0 * (px_in * cin + px * (cout + (cout if res_t is not None else 0))), launch)
 
 
 _WGRAD_WS = {}
