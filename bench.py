@@ -612,6 +612,14 @@ def eval_leg(config, B, rank, world, device, steps, warmup, precision, scaling, 
     g = None
     if graph:
         g, _ = capture_graph(wl)
+        if world > 1:
+            # a capture that fails on ONE rank must not send the ranks down different paths (the eager roofline steps below contain
+            # collectives): everybody replays, or nobody does (as in run_rank)
+            import torch.distributed as dist
+            ok = torch.tensor([1.0 if g is not None else 0.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0:
+                g = None
         graph = g is not None
     select = None if graph else ((lambda n: n == HIDDEN_CONV) if config in ("c3", "c5") else (lambda n: True))
     dt, loss, rows, seen = eval_timed(wl, world, steps, warmup, select, g)
@@ -627,6 +635,8 @@ def eval_leg(config, B, rank, world, device, steps, warmup, precision, scaling, 
             kname, n, ms, fl, by = dominant(rows)
             step_ms = 1e3 * dt if not graph else sum(r[1] for r in rows.values())
             out["roofline"] = roofline_of(kname, n, ms, fl, by, step_ms, precision, B, pmc=(config == "c3"))
+            if graph:
+                out["roofline"]["note"] = "kernel events from 2 eager steps after the timed graph replays; share_of_step = share of GPU kernel time"
     del wl, g
     torch.cuda.empty_cache()
     return out
@@ -719,9 +729,12 @@ def run_rank(args):
     legs = {}
     if default_run and world > 1:
         # BASELINE configs[3]: the SAME global batch of 512 sharded over the ranks; configs[4]: CIFAR d=128, 32 samples per GPU
+        # small shards are launch-latency-sensitive (64 samples: 700 launches in 55 ms): these legs replay a captured HIP graph
+        # (measured on one GPU: 55.0 -> 53.2 ms at 64 samples, 68.9 -> 66.9 ms on the C5 shard; nothing at 512 samples, which stays eager
+        # with the dominant kernel's events inside the timed region)
         legs["strong_c3"] = eval_leg("c3", max(1, 512 // world), rank, world, device, args.leg_steps, 1, args.precision, "strong",
-                                     graph=args.graph, primal=args.primal_precision)
-        legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph, primal=args.primal_precision)
+                                     graph=True, primal=args.primal_precision)
+        legs["c5"] = eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=True, primal=args.primal_precision)
     stages = None
     if rank == 0 and not args.train and not args.no_kernel_timer and not args.hutchinson:
         stages = guarded("stages", lambda: stages_leg(wl, 1e3 * dt / args.steps), 1)
@@ -766,7 +779,7 @@ def run_rank(args):
 
         if not args.no_f32_exact:
             f32 = guarded("f32_exact", f32_exact, world)
-        legs["c5"] = guarded("c5", lambda: eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=args.graph,
+        legs["c5"] = guarded("c5", lambda: eval_leg("c5", 32, rank, world, device, args.leg_steps, 1, args.precision, "weak", graph=True,
                                                      primal=args.primal_precision), world)
         legs["c2b"] = guarded("c2b", lambda: eval_leg("c2b", 4096, rank, world, device, 20, 2, args.precision, "weak", graph=True), world)
         legs["c5_train"] = guarded("c5_train", c5_train, world)

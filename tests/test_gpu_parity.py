@@ -416,6 +416,7 @@ def test_bench_contract_line():
         assert (e.get("per_gpu_batch") or e["config"].get("per_gpu_batch")) == per_gpu
     assert d["c5"]["roofline"]["bound"] == "mfma" and 0 < d["c5"]["roofline"]["frac"] < 1 and d["c5"]["roofline"]["traffic"] is None
     assert d["c2b"]["roofline"]["frac"] > 0 and "graph" in d["c2b"]["config"]["workload"]
+    assert "graph" in d["c5"]["config"]["workload"] and "eager steps" in d["c5"]["roofline"]["note"]      # round 5: the small shard replays a graph
     assert d["c5_train"]["config"]["peak_memory_gib"] < 30 and "Hutchinson" in d["c5_train"]["config"]["workload"]
     assert "kernel source" in (d["roofline"].get("traffic_source") or "")
 
