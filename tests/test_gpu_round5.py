@@ -346,3 +346,28 @@ def test_first_coupler_on_its_live_seed_columns_is_bit_identical(name, B):
     want = torch.zeros(150, 64)
     want[:, sel] = src.data.view(150, 32).cpu()[:, cmap[sel].long()]
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("B,H,W,nc", [(1, 2, 14, 16), (2, 28, 14, 128), (5, 4, 8, 16), (1, 12, 32, 64), (2, 14, 28, 48), (7, 2, 28, 16), (1, 8, 16, 80)])
+def test_checkerboard_output_odd_sizes(B, H, W, nc):
+    """More shapes of the checkerboard-output form: one tile, one sample, 1 / 3 / 5 / 8 column slices, non-square images, both tile
+    families; both parities, relu' from bits, with residual: compact == full launch at the live pixels, bit for bit."""
+    from cmf_amd import engine as E
+    gen = torch.Generator().manual_seed(B * 1000 + H * 10 + W + nc)
+    C, HW, S = 64, H * W, nc // 16
+    x = torch.randn(B, HW, S, C, 16, generator=gen).cuda()                      # slice-major [px][slice][ch][16]
+    res = torch.randn(B, HW, S, C, 16, generator=gen).cuda()
+    prim = torch.randn(B, C, H, W, generator=gen).cuda()
+    wd = torch.nn.Parameter((torch.randn(C, C, 3, 3, generator=gen) / 24).cuda())
+    st, sl = (C * HW * nc, 16, C * nc), C * 16
+    bits = E.relu_bits(prim)
+    fk = dict(fmode=E.F_RELU_BITS, f=bits.data, f_np=bits.np_bytes)
+    full = torch.empty(B, HW, S, C, 16, device="cuda")
+    E.conv_tangent(x, 0, *st, wd, 9, full, *st, B, C, C, H, W, nc, res_t=res, x_sl=sl, y_sl=sl, precision="bf16x3", **fk)
+    ii, jj = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    for live in (1, 2):
+        comp = torch.full((B, HW // 2, S, C, 16), float("nan"), device="cuda")
+        E.conv_tangent(x, 0, *st, wd, 9, comp, st[0] // 2, st[1], st[2], B, C, C, H, W, nc, res_t=res, x_sl=sl, y_sl=sl, precision="bf16x3",
+                       live=live, res_np=st[0], **fk)
+        sel = ((ii + jj) % 2 == live - 1).reshape(-1).cuda()
+        assert torch.equal(comp, full[:, sel]), (B, H, W, nc, live)
