@@ -162,11 +162,14 @@ class AffineCouplingBijection(Bijection):
             # first layer of the decode sweep (FlowProgram._seed_columns): T holds the tail's one-hot seeds, and only the columns
             # seeded at a pass-through element have a non-zero network tangent -- the network runs on those, packed
             sc = seed_columns
-            Tc = E.seed_tangent(T.B, T.N, sc["nc"], T.layout, sc["col_of"], sc["n"], z.device)
-            YTc = E.net_tangent(self.net, Tc, view, acts)
-            YT = E.expand_columns(YTc, T.nc, sc["colmap"])
-            YT.compact = getattr(YTc, "compact", False)
-            self._acl_tangent(T, YT, z, y, g)
+            if sc["n"] == 0:                                         # no latent sits on a pass-through element: no network tangent at all
+                E.acl_tangent(T, None, z, y, g, self.maps(z.device))
+            else:
+                Tc = E.seed_tangent(T.B, T.N, sc["nc"], T.layout, sc["col_of"], sc["n"], z.device)
+                YTc = E.net_tangent(self.net, Tc, view, acts)
+                YT = E.expand_columns(YTc, T.nc, sc["colmap"])
+                YT.compact = getattr(YTc, "compact", False)
+                self._acl_tangent(T, YT, z, y, g)
         elif T is not None:
             YT = E.net_tangent(self.net, T, view, acts)
             self._acl_tangent(T, YT, z, y, g)                       # uses z BEFORE the primal update

@@ -371,3 +371,41 @@ def test_checkerboard_output_odd_sizes(B, H, W, nc):
                        live=live, res_np=st[0], **fk)
         sel = ((ii + jj) % 2 == live - 1).reshape(-1).cuda()
         assert torch.equal(comp, full[:, sel]), (B, H, W, nc, live)
+
+
+def test_seed_column_plan_follows_the_permutation_buffer():
+    """A new permutation written into the tail's buffer (``load_state_dict`` does exactly that) gives a new plan -- the cache is keyed on
+    the buffer's version -- and the packed form stays bit-identical to the full one for every draw, incl. one with NO live column."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build("c3_mnist_full")
+    head = find_head(dens)
+    prog = head.program
+    x = _batch(g, 16)
+    tail, first = prog.tail, prog.layers[-1]
+    gen = torch.Generator().manual_seed(9)
+    seen = set()
+    mod = torch.from_numpy(first._maps._host["zi"]).long()                      # modified elements of the first decoded coupler
+    for draw in range(4):
+        perm = torch.randperm(tail.flattened_dims, generator=gen)
+        if draw == 3:                                                            # every latent on a MODIFIED element: no live column
+            rest = torch.tensor(sorted(set(range(tail.flattened_dims)) - set(mod[: prog.d].tolist())))
+            perm = torch.cat((mod[: prog.d], rest))
+        with torch.no_grad():
+            tail.permutation.copy_(perm.cuda())
+            tail.inverse_permutation.copy_(torch.argsort(perm).cuda())
+        plan = prog._seed_columns(x.device)
+        seen.add(None if plan is None else (plan["n"], plan["nc"]))
+        if draw == 3:
+            assert plan is not None and plan["n"] == 0 and plan["nc"] == 16
+        outs = []
+        with torch.no_grad():
+            z_low = prog.encode(x)[0]
+            for mode in (True, False):
+                prog.SEED_COLUMNS = mode
+                try:
+                    x_hat, T = prog.decode(z_low, tangents=True)
+                finally:
+                    del prog.SEED_COLUMNS
+                outs.append((x_hat.clone(), T.to_dense(prog.d).clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), draw
+    assert len(seen) >= 2
