@@ -409,3 +409,31 @@ def test_seed_column_plan_follows_the_permutation_buffer():
                 outs.append((x_hat.clone(), T.to_dense(prog.d).clone()))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), draw
     assert len(seen) >= 2
+
+
+@pytest.mark.parametrize("tangent,primal", [("f32", "f32"), ("f32", "f16x3"), ("bf16x3", "f32")])
+@pytest.mark.parametrize("name,B", [("c3_mnist_full", 16), ("c5_cifar_full", 3)])
+def test_all_skipping_forms_under_the_other_kernel_configs(name, B, tangent, primal, monkeypatch):
+    """Structural zeros + checkerboard tail + seed columns together against none of them, under the exact-fp32 tangent kernel and
+    the exact-fp32 primal kernel (``head.kernels``): x_hat, J, J^T J, elbo ``torch.equal``."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    head.kernels = E.KernelConfig(tangent=tangent, primal=primal)
+    prog = head.program
+    x = _batch(g, B)
+    outs = []
+    with torch.no_grad():
+        z_low = prog.encode(x)[0]
+        for on in (True, False):
+            monkeypatch.setattr(E, "CHECKERBOARD_TAIL", on)
+            prog.SKIP_STRUCTURAL_ZEROS = prog.SEED_COLUMNS = on
+            try:
+                x_hat, T = prog.decode(z_low, tangents=True)
+                gr = E.gram_cholesky(T, prog.d)
+                elbo = head.elbo(x.clone(), add_offdiagonal_metric_reg=True)["elbo"]
+            finally:
+                del prog.SKIP_STRUCTURAL_ZEROS, prog.SEED_COLUMNS
+            outs.append((x_hat.clone(), T.to_dense(prog.d).clone(), gr.jtj.clone(), elbo.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), (name, tangent, primal, rel(a, b))
