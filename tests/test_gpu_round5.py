@@ -437,3 +437,26 @@ def test_all_skipping_forms_under_the_other_kernel_configs(name, B, tangent, pri
             outs.append((x_hat.clone(), T.to_dense(prog.d).clone(), gr.jtj.clone(), elbo.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b), (name, tangent, primal, rel(a, b))
+
+
+@pytest.mark.parametrize("name", ["mini_mnist", "mini_cifar_cond1e3", "c3_mnist_full", "c5_cifar_full"])
+def test_reference_vectors_through_the_full_forms_too(name, monkeypatch):
+    """The fixture tests run through the skipping forms (the defaults); here the same reference vectors through the FULL forms
+    (every switch off), so that the rounds 1 - 4 path stays pinned as well."""
+    from cmf_amd import engine as E
+    g, meta, cfg, dens = build(name)
+    head = find_head(dens)
+    prog = head.program
+    monkeypatch.setattr(E, "CHECKERBOARD_TAIL", False)
+    prog.SKIP_STRUCTURAL_ZEROS = prog.SEED_COLUMNS = False
+    dequant = "noise" in g
+    x = (g["x"] + g["noise"]) if dequant else g["x"]
+    core = dens.module.density if dequant else dens
+    with torch.no_grad():
+        for i, (lw, mw, rec, off, diag) in enumerate(meta["elbo_combos"]):
+            out = core.elbo(x.cuda(), likelihood_wt=lw, metric_wt=mw, add_reconstruction=rec, add_offdiagonal_metric_reg=off,
+                            add_diagonal_metric_reg=diag)
+            assert rel(out["elbo"], g[f"elbo_{i}"]) < 1e-4, (name, i)
+        x_hat, T = prog.decode(g["z_low"].cuda(), tangents=True)
+        gf = E.gram_cholesky(T, prog.d)
+        assert rel(x_hat, g["x_hat"]) < 1e-5 and rel(gf.jtj, g["jtj"]) < 1e-4 and rel(gf.logdet.view(-1, 1), g["logdet"]) < 1e-4
